@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native DMR demodulation hot path.
+
+Metric (BASELINE.json): Msamples/s of complex input through the FIR->demod chain
+@256 taps, with the fraction of the HBM roofline, at 1/2/4/8 GPUs.
+
+Workload (config.workload = BASELINE.json configs[1]):
+  freq_xlating_fir_filter_ccc (256 taps, decim 4) -> quadrature_demod_cf on
+  synthetic 10 MS/s 4FSK IQ captures of 10 M samples each.  One "step" = one
+  pass of the fused hot-path kernel over a batch of `--captures` independent
+  captures that are already resident in HBM; every capture starts from fresh
+  block state (rotator phase 1, demod history 0), exactly like a fresh
+  flowgraph per capture.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL).  The
+streams are independent units, so ranks shard captures with no data-path
+collective ("scaling": "weak": per-GPU work is fixed); the only collective is
+the RCCL broadcast of the shared taps from rank 0 at set-up.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import grhip_loader  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_VALU_PEAK_TFLOPS = 157.3  # spec, vector fp32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--captures", type=int, default=16, help="captures per GPU per step")
+    ap.add_argument("--samples", type=int, default=10_000_000, help="complex samples per capture")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=10_000_000)
+    return ap.parse_args()
+
+
+def synth_captures(torch, wl, n_caps, n_samples, first_stream_id, device):
+    """4FSK captures synthesised on the device with torch (workload generation is
+    not on the measured path).  Same modulation as workload.fsk4_capture."""
+    c = wl.CFG2
+    sps = int(round(c["fs"] / c["sym_rate"]))
+    n_syms = (n_samples + sps - 1) // sps + 1
+    out = torch.empty((n_caps, n_samples, 2), dtype=torch.float32, device=device)
+    n0 = sps / (10.0 ** (c["esn0_db"] / 10.0))
+    sigma = math.sqrt(n0 / 2.0)
+    for k in range(n_caps):
+        sid = first_stream_id + k
+        sym = torch.from_numpy(wl.fsk4_symbols(n_syms, wl.SEED_BASE + sid)).to(device)
+        f_inst = c["carrier"] + c["deviation"] * sym.repeat_interleave(sps)[:n_samples]
+        ph = torch.cumsum(f_inst.double() * (2 * math.pi / c["fs"]), 0)
+        ph = torch.remainder(ph, 2 * math.pi)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(wl.SEED_BASE + sid)
+        noise = torch.randn((n_samples, 2), generator=gen, device=device, dtype=torch.float32) * sigma
+        out[k, :, 0] = torch.cos(ph).float() + noise[:, 0]
+        out[k, :, 1] = torch.sin(ph).float() + noise[:, 1]
+        del ph, f_inst, noise
+    return out
+
+
+def cpu_baseline(wl, x_host, proto, repeats=2):
+    """CPU path on the host cores of this box, rank 0 only.  Prefers the
+    reference's own SSE dot-product + rotator + atan code (oracle/_ref, kind
+    "reference"); falls back to this repo's generic-order port (kind "port")."""
+    po = grhip_loader.import_oracle()
+    c = wl.CFG2
+    lib = "ref" if po.have_ref() else "oracle"
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], x_host, lib=lib)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    res = {
+        "value": len(x_host) / best / 1e6, "unit": "Msamples/s", "cores": 1,
+        "kind": "reference" if lib == "ref" else "port",
+        "sample": "%d-sample capture, best of %d, single thread; %s" % (
+            len(x_host), repeats,
+            "reference ccomplex_dotprod_sse64.S + gr_rotator.h + gr_fast_atan2f.cc (oracle/_ref)"
+            if lib == "ref" else "generic-order C port (oracle/liboracle.so)"),
+    }
+    # all host cores, one independent stream per thread (ctypes releases the GIL)
+    try:
+        import threading
+        ncpu = os.cpu_count() or 1
+        sub = x_host[: max(len(x_host) // 4, 1_000_000)]
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=po.chain_xlating_demod,
+                                args=(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], sub),
+                                kwargs={"lib": lib}) for _ in range(ncpu)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        dt = time.perf_counter() - t0
+        res["all_cores"] = {"value": ncpu * len(sub) / dt / 1e6, "cores": ncpu,
+                            "sample": "%d streams x %d samples" % (ncpu, len(sub))}
+    except Exception as e:  # pragma: no cover
+        res["all_cores"] = {"error": str(e)}
+    return res
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    g = grhip_loader.import_grhip()
+    wl = g.workload
+    c = wl.CFG2
+
+    # shared taps: built on rank 0, RCCL-broadcast over xGMI to the other ranks
+    proto_t = torch.zeros((c["ntaps"], 2), dtype=torch.float32, device=dev)
+    if rank == 0:
+        proto_t.copy_(torch.from_numpy(wl.cfg2_proto_taps().view(np.float32).reshape(-1, 2)))
+    if world > 1:
+        dist.broadcast(proto_t, src=0)
+    proto = proto_t.cpu().numpy().reshape(-1).view(np.complex64)
+
+    n = a.samples
+    B = a.captures
+    hist = len(proto) - 1
+    nout = n // c["decim"]
+    # captures in HBM, each with its ntaps-1 history zeros in front (what the
+    # scheduler presents to a fresh block, runtime/gr_flat_flowgraph.cc:150)
+    row = ((hist + n + 63) // 64) * 64
+    buf = torch.zeros((B, row, 2), dtype=torch.float32, device=dev)
+    caps = synth_captures(torch, wl, B, n, rank * B, dev)
+    buf[:, hist:hist + n, :] = caps
+    x0_host = caps[0].cpu().numpy().reshape(-1).view(np.complex64).copy() if rank == 0 else None
+    del caps
+    out = torch.empty((B, ((nout + 63) // 64) * 64), dtype=torch.float32, device=dev)
+
+    blk = g.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], device=local_rank)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        for b in range(B):
+            blk.reset()
+            blk.work_device(nout, buf[b], out[b], stream)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(a.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_samples = float(world) * B * n * a.steps
+        value = total_samples / elapsed / 1e6
+        launches = B * a.steps
+        k_ms = dev_ms / launches                      # the only kernel in the timed region
+        alg_bytes = (8.0 + 4.0 / c["decim"]) * n      # 9 B per input sample, fused
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        flops = (2.0 * 2.0 * c["ntaps"] / c["decim"] + 8.0) * n   # pre-mix + real-tap MACs
+        res = {
+            "metric": "Msamples/s through FIR->demod chain @256 taps",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "freq_xlating_fir_filter_ccc 256-tap decim=4 + quadrature_demod_cf, "
+                                   "10 MS/s synthetic 4FSK IQ", "captures_per_gpu_per_step": B,
+                       "samples_per_capture": n, "sharding": "independent captures per rank, "
+                       "RCCL broadcast of taps only"},
+            "roofline": {"bound": "hbm", "kernel": "fir_tiled_kernel<D=4,premix,rotate+demod>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "valu_tflops": flops / (k_ms * 1e-3) / 1e12,
+                         "valu_frac_of_fp32_peak": flops / (k_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wl, x0_host[: a.cpu_samples], proto)
+            res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

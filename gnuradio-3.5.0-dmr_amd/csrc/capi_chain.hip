@@ -1,0 +1,154 @@
+// capi_chain.hip -- the full DMR chain as one device-resident pipeline over a
+// batch of independent captures:
+//   freq_xlating_fir_filter_ccc -> quadrature_demod_cf (one fused kernel)
+//   -> clock_recovery_mm_ff (one wavefront per stream)
+//   -> binary_slicer_fb -> correlate_access_code_bb (one fused kernel)
+// Streams are independent units; batching them is what fills the
+// device for the serial M&M stage.
+#include <complex>
+
+#include "digital_kernels.h"
+#include "fir_kernels.h"
+#include "grhip_internal.h"
+#include "xlating_core.h"
+
+using namespace grhip;
+
+namespace grhip {
+int mm_init_state(MMState &s, float omega, float gain_omega, float mu, float gain_mu, float rel);
+int corr_set_code(CorrParams &p, unsigned long long &flag_bit, const char *code, size_t len);
+}
+
+struct grhip_dmr_chain : HandleBase {
+    XlatingCore core;
+    float gain = 1.f;
+    MMState mm_init;
+    CorrParams cp;
+    int S = 1;
+    size_t max_samples = 0, max_out = 0;
+    const DeviceTables *tabs = nullptr;
+    DevBuf d_demod, d_soft, d_mm, d_mm_init, d_counts, d_ystate, d_corr;
+    size_t out_stride = 0;
+};
+
+extern "C" {
+
+int grhip_dmr_chain_create(grhip_dmr_chain **h, const grhip_dmr_chain_params *p, int n_streams,
+                           size_t max_samples_per_stream, int device)
+{
+    if (!h || !p) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    if (n_streams < 1) return fail(GRHIP_EINVAL, "n_streams must be >= 1");
+    if (p->decimation < 1) return fail(GRHIP_EINVAL, "decimation must be >= 1");
+    if (p->ntaps && !p->taps) return fail(GRHIP_EINVAL, "taps is NULL");
+    MMState ms;
+    int rc = mm_init_state(ms, p->omega, p->gain_omega, p->mu, p->gain_mu, p->omega_relative_limit);
+    if (rc) return rc;
+    CorrParams cp;
+    memset(&cp, 0, sizeof(cp));
+    unsigned long long fb = 0;
+    rc = corr_set_code(cp, fb, p->access_code, p->access_code_len);
+    if (rc) return rc;
+    cp.threshold = (unsigned)p->threshold;
+
+    auto *c = new (std::nothrow) grhip_dmr_chain();
+    if (!c) return fail(GRHIP_ENOMEM, "alloc");
+    c->gain = p->demod_gain; c->mm_init = ms; c->cp = cp; c->S = n_streams;
+    c->max_samples = max_samples_per_stream;
+    c->max_out = max_samples_per_stream / p->decimation;
+    c->out_stride = ((c->max_out + 63) / 64) * 64 + 64;     // 16-byte aligned rows
+    rc = c->init_device(device);
+    if (!rc) rc = get_device_tables(device, &c->tabs);
+    if (!rc) {
+        c->core.decim = p->decimation;
+        c->core.proto.assign((const std::complex<float> *)p->taps, (const std::complex<float> *)p->taps + p->ntaps);
+        c->core.center_freq = p->center_freq; c->core.sampling_freq = p->sampling_freq;
+        rc = c->core.build(device);
+    }
+    if (!rc && !c->core.use_tiled)
+        rc = fail(GRHIP_EINVAL, "dmr_chain needs a decimation/tap count the tiled FIR supports");
+    size_t S = (size_t)n_streams;
+    if (!rc) rc = c->d_demod.reserve(S * c->out_stride * 4);
+    if (!rc) rc = c->d_soft.reserve(S * c->out_stride * 4);
+    if (!rc) rc = c->d_mm.reserve(S * sizeof(MMState));
+    if (!rc) rc = c->d_mm_init.reserve(S * sizeof(MMState));
+    if (!rc) rc = c->d_counts.reserve(S * 2 * sizeof(int));
+    if (!rc) rc = c->d_ystate.reserve(S * 2 * sizeof(float2));
+    if (!rc) rc = c->d_corr.reserve(S * sizeof(CorrState));
+    if (!rc) {
+        std::vector<MMState> init(S, ms);
+        hipError_t e = hipMemcpy(c->d_mm_init.p, init.data(), S * sizeof(MMState), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(GRHIP_ERUNTIME, "state upload");
+    }
+    if (rc) { grhip_dmr_chain_destroy(c); return rc; }
+    *h = c;
+    return GRHIP_OK;
+}
+
+void grhip_dmr_chain_destroy(grhip_dmr_chain *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    h->core.release();
+    h->d_demod.release(); h->d_soft.release(); h->d_mm.release(); h->d_mm_init.release();
+    h->d_counts.release(); h->d_ystate.release(); h->d_corr.release();
+    h->destroy_base();
+    delete h;
+}
+
+int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_samples,
+                               size_t stream_stride_items, unsigned char *d_bits, size_t bits_stride,
+                               int *d_nbits, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (n_samples > h->max_samples) return fail(GRHIP_EINVAL, "n_samples exceeds max_samples_per_stream");
+    int rc = h->bind();
+    if (rc) return rc;
+    hipStream_t st = h->pick(stream);
+    const size_t S = (size_t)h->S;
+    const long long n_out = (long long)(n_samples / h->core.decim);
+    if (n_out <= 0) { GRHIP_HIP(hipMemsetAsync(d_nbits, 0, S * sizeof(int), st)); return GRHIP_OK; }
+    if ((size_t)n_out > bits_stride) return fail(GRHIP_EINVAL, "bits_stride too small");
+
+    // fresh block state for every capture
+    h->core.reset();
+    GRHIP_HIP(hipMemsetAsync(h->d_ystate.p, 0, S * 2 * sizeof(float2), st));
+    GRHIP_HIP(hipMemcpyAsync(h->d_mm.p, h->d_mm_init.p, S * sizeof(MMState), hipMemcpyDeviceToDevice, st));
+    GRHIP_HIP(hipMemsetAsync(h->d_corr.p, 0, S * sizeof(CorrState), st));
+
+    // 1) xlating + quad demod; the ntaps-1 history zeros are synthesised by n_lo
+    const long long hist = h->core.ntaps > 0 ? h->core.ntaps - 1 : 0;
+    const float2 *x = (const float2 *)d_in - hist;
+    float2 *ys = h->d_ystate.as<float2>();
+    rc = h->core.run(GRHIP_MODE_FAST, x, hist + (long long)n_samples, n_out, nullptr, h->d_demod.as<float>(),
+                     h->gain, ys, ys + S, h->tabs->atan_tab, st, h->S, (long long)stream_stride_items, hist,
+                     (long long)h->out_stride);
+    if (rc) return rc;
+
+    // 2) M&M clock recovery, one wavefront per stream
+    rc = launch_mm(h->d_mm.as<MMState>(), h->S, (int)n_out, (int)n_out, h->d_demod.as<float>(),
+                   (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
+                   h->d_counts.as<int>(), h->tabs->mmse_rev, st);
+    if (rc) return rc;
+
+    // 3) slicer + access-code correlator on the symbols each stream produced
+    rc = launch_correlate(h->cp, h->d_corr.as<CorrState>(), h->S, nullptr, h->d_soft.as<float>(),
+                          (long long)h->out_stride, d_bits, (long long)bits_stride, n_out,
+                          h->d_counts.as<int>(), 2, st);
+    if (rc) return rc;
+    GRHIP_HIP(hipMemcpy2DAsync(d_nbits, sizeof(int), h->d_counts.p, 2 * sizeof(int), sizeof(int), S,
+                               hipMemcpyDeviceToDevice, st));
+    return GRHIP_OK;
+}
+
+int grhip_dmr_chain_intermediate(grhip_dmr_chain *h, int which, void **d_ptr, size_t *stride)
+{
+    if (!h || !d_ptr || !stride) return fail(GRHIP_EINVAL, "null argument");
+    *stride = h->out_stride;
+    if (which == 0) *d_ptr = h->d_demod.p;
+    else if (which == 1) *d_ptr = h->d_soft.p;
+    else return fail(GRHIP_EINVAL, "which must be 0 or 1");
+    return GRHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,721 @@
+// capi_fir.hip -- C ABI for gr_fir_filter_XXX, gr_freq_xlating_fir_filter_ccc,
+// gr_quadrature_demod_cf and the fused xlating->demod hier block.
+#include <cmath>
+#include <complex>
+
+#include "fir_kernels.h"
+#include "grhip_internal.h"
+#include "xlating_core.h"
+
+using namespace grhip;
+typedef std::complex<float> cf;
+
+namespace grhip {
+
+// ---- tap packing for the tiled kernel ---------------------------------------
+// c[k] multiplies x[nD + k]; hp[p*Tq + q] = c[qD + p], zero padded.
+static int pack_phase_major(const float *c, int T, int tw, int D, std::vector<float> &hp)
+{
+    int R = tiled_R();
+    int per = (T + D - 1) / D;
+    int Tq = ((per + R - 1) / R) * R;
+    if (Tq == 0) Tq = R;
+    hp.assign((size_t)D * Tq * tw, 0.f);
+    for (int k = 0; k < T; ++k) {
+        int p = k % D, q = k / D;
+        for (int w = 0; w < tw; ++w) hp[((size_t)p * Tq + q) * tw + w] = c[(size_t)k * tw + w];
+    }
+    return Tq;
+}
+
+static int upload(DevBuf &b, const void *src, size_t bytes)
+{
+    int rc = b.reserve(bytes ? bytes : 16);
+    if (rc) return rc;
+    if (bytes) GRHIP_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return GRHIP_OK;
+}
+
+// ============================================================================
+// XlatingCore
+// ============================================================================
+int XlatingCore::build(int device)
+{
+    // build_composite_fir (filter/gr_freq_xlating_fir_filter_XXX.cc.t:72-83)
+    ntaps = (int)proto.size();
+    ctaps.resize(ntaps);
+    float fwT0 = 2 * M_PI * center_freq / sampling_freq;
+    for (unsigned i = 0; i < (unsigned)ntaps; i++) {
+        cf e = std::exp(cf(0, i * fwT0));
+        // complex product in libgcc order (ac - bd, ad + bc)
+        float a = proto[i].real(), b = proto[i].imag(), c = e.real(), d = e.imag();
+        float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+        ctaps[i] = cf(ac - bd, ad + bc);
+    }
+    // d_r.set_phase_incr(exp(gr_complex(0, fwT0 * decimation()))) ; incr / abs(incr)
+    cf inc = std::exp(cf(0, fwT0 * decim));
+    float mag = hypotf(inc.real(), inc.imag());
+    incr = cf(inc.real() / mag, inc.imag() / mag);
+    omega = (double)fwT0;
+
+    // device copies
+    // generic kernel wants d_taps order; after reverse(reverse()) that is ctaps itself
+    int rc = upload(d_taps_generic, ctaps.data(), sizeof(cf) * ntaps);
+    if (rc) return rc;
+
+    bool real_proto = true;
+    for (auto &t : proto) if (t.imag() != 0.0f) real_proto = false;
+    std::vector<float> hp;
+    use_tiled = false; premix = false;
+    if (ntaps > 0) {
+        if (real_proto) {
+            std::vector<float> pr(ntaps);
+            for (int i = 0; i < ntaps; ++i) pr[i] = proto[i].real();
+            Tq = pack_phase_major(pr.data(), ntaps, 1, decim, hp);
+            if (tiled_supported(decim, Tq)) { use_tiled = true; premix = true; }
+        }
+        if (!use_tiled) {
+            Tq = pack_phase_major((const float *)ctaps.data(), ntaps, 2, decim, hp);
+            if (tiled_supported(decim, Tq)) use_tiled = true;
+        }
+    }
+    if (use_tiled) {
+        rc = upload(d_hp, hp.data(), hp.size() * sizeof(float));
+        if (rc) return rc;
+        if (premix) {
+            // W[u] = exp(j w (u - D)),  V[j'] = exp(-j w (j'-1) D), computed in double
+            const int NT = tiled_NT();
+            const int Lu = (NT + Tq) * decim;
+            std::vector<cf> W(Lu), V(NT + 1);
+            for (int u = 0; u < Lu; ++u) {
+                double ang = omega * (double)(u - decim);
+                W[u] = cf((float)cos(ang), (float)sin(ang));
+            }
+            for (int j = 0; j <= NT; ++j) {
+                double ang = -omega * (double)(j - 1) * (double)decim;
+                V[j] = cf((float)cos(ang), (float)sin(ang));
+            }
+            rc = upload(d_wtab, W.data(), W.size() * sizeof(cf));
+            if (rc) return rc;
+            rc = upload(d_vtab, V.data(), V.size() * sizeof(cf));
+            if (rc) return rc;
+        }
+    }
+    reset();
+    (void)device;
+    return GRHIP_OK;
+}
+
+void XlatingCore::reset()
+{
+    pos = 0;
+    if (tab_start != 0) { tab_start = 0; tab_len = 0; }
+    if (tab_len == 0) { gen_phase = cf(1.f, 0.f); gen_counter = 0; }
+    if (built_incr != incr) {   // a table generated for another increment is useless
+        tab_start = 0; tab_len = 0; gen_phase = cf(1.f, 0.f); gen_counter = 0;
+        built_incr = incr;
+    }
+}
+
+// make sure d_rot covers outputs [pos, pos+n); *gtab = device pointer of phase(pos)
+int XlatingCore::ensure_rot(long long n, const float2 **gtab)
+{
+    const long long CAP = 1ll << 25;
+    if (pos < tab_start) { tab_start = 0; tab_len = 0; gen_phase = cf(1.f, 0.f); gen_counter = 0; }
+    long long tab_end = tab_start + tab_len;
+    if (pos + n > tab_end) {
+        if (pos == tab_end && tab_len > 0 && (pos + n - tab_start) > CAP) {
+            tab_start = pos; tab_len = 0;   // re-anchor, generator state is already at pos
+        }
+        long long need = pos + n - (tab_start + tab_len);
+        std::vector<cf> fresh((size_t)need);
+        // gr_rotator::rotate (filter/gr_rotator.h:40-50), exact float recurrence
+        float pr = gen_phase.real(), pi = gen_phase.imag();
+        const float ir = incr.real(), ii = incr.imag();
+        unsigned cnt = gen_counter;
+        for (long long i = 0; i < need; ++i) {
+            fresh[(size_t)i] = cf(pr, pi);
+            cnt++;
+            float ac = pr * ir, bd = pi * ii, ad = pr * ii, bc = pi * ir;
+            pr = ac - bd; pi = ad + bc;
+            if ((cnt % 512) == 0) {
+                float a = hypotf(pr, pi);
+                pr = pr / a; pi = pi / a;
+            }
+        }
+        gen_phase = cf(pr, pi); gen_counter = cnt;
+        size_t new_items = (size_t)(tab_len + need);
+        if (new_items * sizeof(cf) > d_rot.cap) {
+            DevBuf nb;
+            int rc = nb.reserve(new_items * sizeof(cf) * 2);
+            if (rc) return rc;
+            if (tab_len) GRHIP_HIP(hipMemcpy(nb.p, d_rot.p, (size_t)tab_len * sizeof(cf), hipMemcpyDeviceToDevice));
+            d_rot.release();
+            d_rot = nb;
+        }
+        GRHIP_HIP(hipMemcpy(d_rot.as<cf>() + tab_len, fresh.data(), (size_t)need * sizeof(cf),
+                            hipMemcpyHostToDevice));
+        tab_len += need;
+    }
+    *gtab = reinterpret_cast<const float2 *>(d_rot.as<cf>() + (pos - tab_start));
+    return GRHIP_OK;
+}
+
+void XlatingCore::release()
+{
+    d_taps_generic.release(); d_hp.release(); d_wtab.release(); d_vtab.release(); d_rot.release();
+    scratch_y.release();
+}
+
+// run the FIR + rotator (+ demod) for n_out outputs on device pointers.
+// d_in item 0 = input[0] of output 0; n_in readable items.
+int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_out, float2 *d_y,
+                     float *d_demod, float gain, const float2 *y_prev, float2 *y_last,
+                     const float *atan_tab, hipStream_t st, int n_streams, long long x_stride,
+                     long long n_lo, long long out_stride)
+{
+    if (n_out <= 0) return GRHIP_OK;
+    const float2 *gtab = nullptr;
+    int rc = ensure_rot(n_out, &gtab);
+    if (rc) return rc;
+    const bool demod = d_demod != nullptr;
+    if (mode == GRHIP_MODE_FAST && use_tiled) {
+        FirTiledArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = d_in; a.x_stride = x_stride; a.n_in = n_in; a.n_lo = n_lo;
+        a.hp = d_hp.as<float>(); a.Tq = Tq; a.n_out = n_out;
+        a.wtab = d_wtab.as<float2>(); a.vtab = d_vtab.as<float2>(); a.gtab = gtab;
+        a.y_out = d_y; a.d_out = d_demod; a.gain = gain;
+        a.y_stride = out_stride; a.d_stride = out_stride;
+        a.y_prev = y_prev; a.y_last = y_last; a.atan_tab = atan_tab;
+        uintptr_t o = demod ? (uintptr_t)d_demod : (uintptr_t)d_y;
+        a.vec_store = (o & 15) == 0 && ((out_stride * (demod ? 4 : 8)) & 15) == 0;
+        rc = launch_fir_tiled(decim, !premix, premix, demod ? EPI_ROTATE_DEMOD : EPI_ROTATE, a, n_streams, st);
+        if (rc) return rc;
+    } else {
+        if (n_streams != 1 || n_lo != 0)
+            return fail(GRHIP_EINVAL, "generic-order path runs one stream with explicit history");
+        // generic order (bit-exact) FIR + rotate; demod as a second kernel over y
+        float2 *y = d_y;
+        if (demod) {
+            rc = scratch_y.reserve((size_t)(n_out + 1) * sizeof(float2));
+            if (rc) return rc;
+            y = scratch_y.as<float2>() + 1;
+            GRHIP_HIP(hipMemcpyAsync(scratch_y.p, y_prev, sizeof(float2), hipMemcpyDeviceToDevice, st));
+        }
+        rc = launch_fir_generic(FIR_CCC, d_taps_generic.as<float>(), ntaps, d_in, y, n_out, decim, gtab, st);
+        if (rc) return rc;
+        if (demod) {
+            rc = launch_quad_demod(scratch_y.as<float2>(), d_demod, n_out, gain, atan_tab, st);
+            if (rc) return rc;
+            GRHIP_HIP(hipMemcpyAsync(y_last, y + (n_out - 1), sizeof(float2), hipMemcpyDeviceToDevice, st));
+        }
+    }
+    pos += n_out;
+    return GRHIP_OK;
+}
+
+}  // namespace grhip
+
+// ============================================================================
+// gr_fir_filter_XXX
+// ============================================================================
+struct grhip_fir_filter : HandleBase {
+    FirKind kind;
+    int decim = 1;
+    int mode = GRHIP_MODE_FAST;
+    std::vector<float> taps;        // current forward taps (floats; x2 for ccc)
+    std::vector<float> new_taps;    // latched by set_taps
+    bool updated = false;
+    int ntaps = 0;
+    DevBuf d_taps_rev, d_hp;
+    int Tq = 0;
+    bool use_tiled = false;
+
+    int tw() const { return kind == FIR_CCC ? 2 : 1; }
+    size_t in_item() const { return kind == FIR_FFF ? 4 : 8; }
+    size_t out_item() const { return kind == FIR_FFF ? 4 : 8; }
+
+    int install(const std::vector<float> &t)
+    {
+        taps = t;
+        ntaps = (int)(taps.size() / tw());
+        std::vector<float> rev(taps.size());
+        for (int k = 0; k < ntaps; ++k)
+            for (int w = 0; w < tw(); ++w) rev[(size_t)k * tw() + w] = taps[(size_t)(ntaps - 1 - k) * tw() + w];
+        int rc = upload(d_taps_rev, rev.data(), rev.size() * sizeof(float));
+        if (rc) return rc;
+        use_tiled = false;
+        if (kind != FIR_FFF && ntaps > 0) {
+            std::vector<float> hp;
+            Tq = pack_phase_major(rev.data(), ntaps, tw(), decim, hp);
+            if (tiled_supported(decim, Tq)) {
+                rc = upload(d_hp, hp.data(), hp.size() * sizeof(float));
+                if (rc) return rc;
+                use_tiled = true;
+            }
+        }
+        return GRHIP_OK;
+    }
+
+    int run(const void *d_in, void *d_out, long long n, int dec, hipStream_t st)
+    {
+        if (n <= 0) return GRHIP_OK;
+        if (mode == GRHIP_MODE_FAST && use_tiled && dec == decim) {
+            FirTiledArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = (const float2 *)d_in; a.n_in = (n - 1) * dec + ntaps;
+            a.hp = d_hp.as<float>(); a.Tq = Tq; a.n_out = n;
+            a.y_out = (float2 *)d_out;
+            a.vec_store = (((uintptr_t)d_out) & 15) == 0;
+            return launch_fir_tiled(dec, kind == FIR_CCC, false, EPI_NONE, a, 1, st);
+        }
+        return launch_fir_generic(kind, d_taps_rev.as<float>(), ntaps, d_in, d_out, n, dec, nullptr, st);
+    }
+};
+
+extern "C" {
+
+int grhip_fir_filter_create(grhip_fir_filter **h, const char *kind, int decimation, const float *taps,
+                            size_t ntaps, int device)
+{
+    if (!h || !kind) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    FirKind k;
+    if (!strcmp(kind, "ccf")) k = FIR_CCF;
+    else if (!strcmp(kind, "fff")) k = FIR_FFF;
+    else if (!strcmp(kind, "ccc")) k = FIR_CCC;
+    else return fail(GRHIP_EINVAL, "unknown FIR kind '%s'", kind);
+    if (decimation < 1) return fail(GRHIP_EINVAL, "decimation must be >= 1");
+    if (ntaps && !taps) return fail(GRHIP_EINVAL, "taps is NULL");
+    grhip_fir_filter *f = new (std::nothrow) grhip_fir_filter();
+    if (!f) return fail(GRHIP_ENOMEM, "alloc");
+    f->kind = k; f->decim = decimation; f->mode = default_mode();
+    int rc = f->init_device(device);
+    if (!rc) rc = f->install(std::vector<float>(taps, taps + ntaps * f->tw()));
+    if (rc) { f->d_taps_rev.release(); f->d_hp.release(); f->destroy_base(); delete f; return rc; }
+    *h = f;
+    return GRHIP_OK;
+}
+
+void grhip_fir_filter_destroy(grhip_fir_filter *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    h->d_taps_rev.release(); h->d_hp.release();
+    h->destroy_base();
+    delete h;
+}
+
+int grhip_fir_filter_set_taps(grhip_fir_filter *h, const float *taps, size_t ntaps)
+{
+    if (!h || (ntaps && !taps)) return fail(GRHIP_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(h->setter_mutex);
+    h->new_taps.assign(taps, taps + ntaps * h->tw());   // d_new_taps (.cc.t:59-64)
+    h->updated = true;
+    return GRHIP_OK;
+}
+
+int grhip_fir_filter_set_mode(grhip_fir_filter *h, int mode)
+{
+    if (!h || (mode != GRHIP_MODE_FAST && mode != GRHIP_MODE_GENERIC)) return fail(GRHIP_EINVAL, "bad mode");
+    h->mode = mode;
+    return GRHIP_OK;
+}
+
+int grhip_fir_filter_history(const grhip_fir_filter *h)
+{
+    // set_history(d_fir->ntaps()) (.cc.t:51,77); gr_block history is at least 1
+    return h ? (h->ntaps > 0 ? h->ntaps : 1) : GRHIP_EINVAL;
+}
+
+int grhip_fir_filter_decimation(const grhip_fir_filter *h) { return h ? h->decim : GRHIP_EINVAL; }
+
+static int fir_apply_update(grhip_fir_filter *h)
+{
+    std::lock_guard<std::mutex> lk(h->setter_mutex);
+    if (!h->updated) return 0;
+    int rc = h->install(h->new_taps);
+    if (rc) return rc;
+    h->updated = false;
+    return 1;
+}
+
+int grhip_fir_filter_work_device(grhip_fir_filter *h, int noutput_items, const void *d_in, void *d_out,
+                                 void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    int rc = h->bind();
+    if (rc) return rc;
+    rc = fir_apply_update(h);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;   // history requirements may have changed (.cc.t:74-79)
+    rc = h->run(d_in, d_out, noutput_items, h->decim, h->pick(stream));
+    return rc ? rc : noutput_items;
+}
+
+int grhip_fir_filter_work(grhip_fir_filter *h, int noutput_items, const void *in, void *out)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    int rc = h->bind();
+    if (rc) return rc;
+    rc = fir_apply_update(h);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
+    if (noutput_items == 0) return 0;
+    long long n = noutput_items;
+    size_t n_in = (size_t)((n - 1) * h->decim + (h->ntaps > 0 ? h->ntaps : 0));
+    if (n_in == 0) n_in = 1;
+    if ((rc = h->stage_in.reserve(n_in * h->in_item() + 16))) return rc;
+    if ((rc = h->stage_out.reserve((size_t)n * h->out_item()))) return rc;
+    hipStream_t st = h->own_stream;
+    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n_in * h->in_item(), hipMemcpyHostToDevice, st));
+    if ((rc = h->run(h->stage_in.p, h->stage_out.p, n, h->decim, st))) return rc;
+    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, (size_t)n * h->out_item(), hipMemcpyDeviceToHost, st));
+    GRHIP_HIP(hipStreamSynchronize(st));
+    return noutput_items;
+}
+
+int grhip_fir_filterNdec(grhip_fir_filter *h, void *output, const void *input, unsigned long n,
+                         unsigned decimate)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (decimate < 1) return fail(GRHIP_EINVAL, "decimate must be >= 1");
+    int rc = h->bind();
+    if (rc) return rc;
+    if (n == 0) return GRHIP_OK;
+    size_t n_in = (size_t)((n - 1) * decimate + h->ntaps);
+    if (n_in == 0) n_in = 1;
+    if ((rc = h->stage_in.reserve(n_in * h->in_item() + 16))) return rc;
+    if ((rc = h->stage_out.reserve((size_t)n * h->out_item()))) return rc;
+    hipStream_t st = h->own_stream;
+    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, input, n_in * h->in_item(), hipMemcpyHostToDevice, st));
+    if ((rc = h->run(h->stage_in.p, h->stage_out.p, (long long)n, (int)decimate, st))) return rc;
+    GRHIP_HIP(hipMemcpyAsync(output, h->stage_out.p, (size_t)n * h->out_item(), hipMemcpyDeviceToHost, st));
+    GRHIP_HIP(hipStreamSynchronize(st));
+    return GRHIP_OK;
+}
+
+}  // extern "C"
+
+// ============================================================================
+// gr_freq_xlating_fir_filter_ccc, gr_quadrature_demod_cf, fused hier block
+// ============================================================================
+struct grhip_freq_xlating_fir_filter_ccc : HandleBase {
+    XlatingCore core;
+    int mode = GRHIP_MODE_FAST;
+    // latched by the setters (.cc.t:86-98)
+    std::vector<cf> new_proto; double new_center_freq = 0; bool updated = false;
+};
+
+struct grhip_quadrature_demod_cf : HandleBase {
+    float gain = 1.f;
+    const DeviceTables *tabs = nullptr;
+};
+
+struct grhip_xlating_demod : HandleBase {
+    XlatingCore core;
+    int mode = GRHIP_MODE_FAST;
+    float gain = 1.f;
+    const DeviceTables *tabs = nullptr;
+    DevBuf ystate;   // float2[4]: [0],[1] ping-pong carry of the demodulator's previous
+                     // sample, [2] constant zero (the history item of a fresh block)
+    int cur = 0;
+    bool fresh = true;
+};
+
+static int xlating_args_ok(int decimation, const float *taps, size_t ntaps, double sampling_freq)
+{
+    if (decimation < 1) return fail(GRHIP_EINVAL, "decimation must be >= 1");
+    if (ntaps && !taps) return fail(GRHIP_EINVAL, "taps is NULL");
+    if (sampling_freq == 0.0) return fail(GRHIP_EINVAL, "sampling_freq is 0");
+    return GRHIP_OK;
+}
+
+extern "C" {
+
+int grhip_freq_xlating_fir_filter_ccc_create(grhip_freq_xlating_fir_filter_ccc **h, int decimation,
+                                             const float *taps, size_t ntaps, double center_freq,
+                                             double sampling_freq, int device)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    int rc = xlating_args_ok(decimation, taps, ntaps, sampling_freq);
+    if (rc) return rc;
+    auto *x = new (std::nothrow) grhip_freq_xlating_fir_filter_ccc();
+    if (!x) return fail(GRHIP_ENOMEM, "alloc");
+    x->mode = default_mode();
+    rc = x->init_device(device);
+    if (!rc) {
+        x->core.decim = decimation;
+        x->core.proto.assign((const cf *)taps, (const cf *)taps + ntaps);
+        x->core.center_freq = center_freq; x->core.sampling_freq = sampling_freq;
+        rc = x->core.build(device);
+    }
+    if (rc) { x->core.release(); x->destroy_base(); delete x; return rc; }
+    *h = x;
+    return GRHIP_OK;
+}
+
+void grhip_freq_xlating_fir_filter_ccc_destroy(grhip_freq_xlating_fir_filter_ccc *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    h->core.release();
+    h->destroy_base();
+    delete h;
+}
+
+int grhip_freq_xlating_fir_filter_ccc_set_center_freq(grhip_freq_xlating_fir_filter_ccc *h, double center_freq)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lk(h->setter_mutex);
+    if (!h->updated) h->new_proto = h->core.proto;
+    h->new_center_freq = center_freq;
+    h->updated = true;
+    return GRHIP_OK;
+}
+
+int grhip_freq_xlating_fir_filter_ccc_set_taps(grhip_freq_xlating_fir_filter_ccc *h, const float *taps,
+                                              size_t ntaps)
+{
+    if (!h || (ntaps && !taps)) return fail(GRHIP_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lk(h->setter_mutex);
+    if (!h->updated) h->new_center_freq = h->core.center_freq;
+    h->new_proto.assign((const cf *)taps, (const cf *)taps + ntaps);
+    h->updated = true;
+    return GRHIP_OK;
+}
+
+int grhip_freq_xlating_fir_filter_ccc_set_mode(grhip_freq_xlating_fir_filter_ccc *h, int mode)
+{
+    if (!h || (mode != GRHIP_MODE_FAST && mode != GRHIP_MODE_GENERIC)) return fail(GRHIP_EINVAL, "bad mode");
+    h->mode = mode;
+    return GRHIP_OK;
+}
+
+int grhip_freq_xlating_fir_filter_ccc_history(const grhip_freq_xlating_fir_filter_ccc *h)
+{
+    return h ? (h->core.ntaps > 0 ? h->core.ntaps : 1) : GRHIP_EINVAL;
+}
+
+int grhip_freq_xlating_fir_filter_ccc_reset(grhip_freq_xlating_fir_filter_ccc *h)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    h->core.reset();
+    return GRHIP_OK;
+}
+
+static int xl_apply_update(grhip_freq_xlating_fir_filter_ccc *h)
+{
+    std::lock_guard<std::mutex> lk(h->setter_mutex);
+    if (!h->updated) return 0;
+    // work(): set_history; build_composite_fir(); d_updated = false; return 0 (.cc.t:109-114).
+    // NB the reference keeps the rotator's d_phase/d_counter and only replaces
+    // d_phase_incr; XlatingCore::rebuild_keep_phase does the same.
+    h->core.proto = h->new_proto;
+    h->core.center_freq = h->new_center_freq;
+    int rc = h->core.rebuild_keep_phase(h->device);
+    if (rc) return rc;
+    h->updated = false;
+    return 1;
+}
+
+int grhip_freq_xlating_fir_filter_ccc_work_device(grhip_freq_xlating_fir_filter_ccc *h, int noutput_items,
+                                                  const void *d_in, void *d_out, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    int rc = h->bind();
+    if (rc) return rc;
+    rc = xl_apply_update(h);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
+    long long n = noutput_items;
+    long long n_in = n > 0 ? (n - 1) * h->core.decim + h->core.ntaps : 0;
+    rc = h->core.run(h->mode, (const float2 *)d_in, n_in, n, (float2 *)d_out, nullptr, 0.f, nullptr, nullptr,
+                     nullptr, h->pick(stream));
+    return rc ? rc : noutput_items;
+}
+
+int grhip_freq_xlating_fir_filter_ccc_work(grhip_freq_xlating_fir_filter_ccc *h, int noutput_items,
+                                           const void *in, void *out)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    int rc = h->bind();
+    if (rc) return rc;
+    rc = xl_apply_update(h);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
+    if (noutput_items == 0) return 0;
+    long long n = noutput_items;
+    size_t n_in = (size_t)((n - 1) * h->core.decim + h->core.ntaps);
+    if (n_in == 0) n_in = 1;
+    if ((rc = h->stage_in.reserve(n_in * 8 + 16))) return rc;
+    if ((rc = h->stage_out.reserve((size_t)n * 8))) return rc;
+    hipStream_t st = h->own_stream;
+    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n_in * 8, hipMemcpyHostToDevice, st));
+    rc = h->core.run(h->mode, h->stage_in.as<float2>(), (long long)n_in, n, h->stage_out.as<float2>(), nullptr,
+                     0.f, nullptr, nullptr, nullptr, st);
+    if (rc) return rc;
+    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    GRHIP_HIP(hipStreamSynchronize(st));
+    return noutput_items;
+}
+
+// ---- quadrature_demod_cf -----------------------------------------------------
+int grhip_quadrature_demod_cf_create(grhip_quadrature_demod_cf **h, float gain, int device)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    auto *q = new (std::nothrow) grhip_quadrature_demod_cf();
+    if (!q) return fail(GRHIP_ENOMEM, "alloc");
+    q->gain = gain;
+    int rc = q->init_device(device);
+    if (!rc) rc = get_device_tables(device, &q->tabs);
+    if (rc) { q->destroy_base(); delete q; return rc; }
+    *h = q;
+    return GRHIP_OK;
+}
+
+void grhip_quadrature_demod_cf_destroy(grhip_quadrature_demod_cf *h)
+{
+    if (!h) return;
+    h->destroy_base();
+    delete h;
+}
+
+int grhip_quadrature_demod_cf_work_device(grhip_quadrature_demod_cf *h, int noutput_items, const void *d_in,
+                                          void *d_out, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    int rc = h->bind();
+    if (rc) return rc;
+    rc = launch_quad_demod((const float2 *)d_in, (float *)d_out, noutput_items, h->gain, h->tabs->atan_tab,
+                           h->pick(stream));
+    return rc ? rc : noutput_items;
+}
+
+int grhip_quadrature_demod_cf_work(grhip_quadrature_demod_cf *h, int noutput_items, const void *in, void *out)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    if (noutput_items == 0) return 0;
+    int rc = h->bind();
+    if (rc) return rc;
+    size_t n = (size_t)noutput_items;
+    if ((rc = h->stage_in.reserve((n + 1) * 8))) return rc;
+    if ((rc = h->stage_out.reserve(n * 4))) return rc;
+    hipStream_t st = h->own_stream;
+    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    if ((rc = launch_quad_demod(h->stage_in.as<float2>(), h->stage_out.as<float>(), (long long)n, h->gain,
+                                h->tabs->atan_tab, st)))
+        return rc;
+    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, n * 4, hipMemcpyDeviceToHost, st));
+    GRHIP_HIP(hipStreamSynchronize(st));
+    return noutput_items;
+}
+
+// ---- fused xlating -> demod ----------------------------------------------------
+int grhip_xlating_demod_create(grhip_xlating_demod **h, int decimation, const float *taps, size_t ntaps,
+                               double center_freq, double sampling_freq, float gain, int device)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    int rc = xlating_args_ok(decimation, taps, ntaps, sampling_freq);
+    if (rc) return rc;
+    auto *x = new (std::nothrow) grhip_xlating_demod();
+    if (!x) return fail(GRHIP_ENOMEM, "alloc");
+    x->mode = default_mode();
+    x->gain = gain;
+    rc = x->init_device(device);
+    if (!rc) rc = get_device_tables(device, &x->tabs);
+    if (!rc) {
+        x->core.decim = decimation;
+        x->core.proto.assign((const cf *)taps, (const cf *)taps + ntaps);
+        x->core.center_freq = center_freq; x->core.sampling_freq = sampling_freq;
+        rc = x->core.build(device);
+    }
+    if (!rc) rc = x->ystate.reserve(4 * sizeof(float2));
+    if (!rc) { hipError_t e = hipMemset(x->ystate.p, 0, 4 * sizeof(float2)); if (e != hipSuccess) rc = fail(GRHIP_ERUNTIME, "memset"); }
+    if (rc) { x->core.release(); x->ystate.release(); x->destroy_base(); delete x; return rc; }
+    *h = x;
+    return GRHIP_OK;
+}
+
+void grhip_xlating_demod_destroy(grhip_xlating_demod *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    h->core.release(); h->ystate.release();
+    h->destroy_base();
+    delete h;
+}
+
+int grhip_xlating_demod_set_mode(grhip_xlating_demod *h, int mode)
+{
+    if (!h || (mode != GRHIP_MODE_FAST && mode != GRHIP_MODE_GENERIC)) return fail(GRHIP_EINVAL, "bad mode");
+    h->mode = mode;
+    return GRHIP_OK;
+}
+
+int grhip_xlating_demod_reset(grhip_xlating_demod *h)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    int rc = h->bind();
+    if (rc) return rc;
+    h->core.reset();     // host-side only: no device work, no synchronisation
+    h->fresh = true;
+    return GRHIP_OK;
+}
+
+int grhip_xlating_demod_history(const grhip_xlating_demod *h)
+{
+    return h ? (h->core.ntaps > 0 ? h->core.ntaps : 1) : GRHIP_EINVAL;
+}
+
+int grhip_xlating_demod_work_device(grhip_xlating_demod *h, int noutput_items, const void *d_in, void *d_out,
+                                    void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    if (noutput_items == 0) return 0;
+    int rc = h->bind();
+    if (rc) return rc;
+    long long n = noutput_items;
+    long long n_in = (n - 1) * h->core.decim + h->core.ntaps;
+    float2 *ys = h->ystate.as<float2>();
+    rc = h->core.run(h->mode, (const float2 *)d_in, n_in, n, nullptr, (float *)d_out, h->gain,
+                     h->fresh ? ys + 2 : ys + h->cur, ys + (h->cur ^ 1), h->tabs->atan_tab, h->pick(stream));
+    if (rc) return rc;
+    h->cur ^= 1;
+    h->fresh = false;
+    return noutput_items;
+}
+
+int grhip_xlating_demod_work(grhip_xlating_demod *h, int noutput_items, const void *in, void *out)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    if (noutput_items == 0) return 0;
+    int rc = h->bind();
+    if (rc) return rc;
+    long long n = noutput_items;
+    size_t n_in = (size_t)((n - 1) * h->core.decim + h->core.ntaps);
+    if (n_in == 0) n_in = 1;
+    if ((rc = h->stage_in.reserve(n_in * 8 + 16))) return rc;
+    if ((rc = h->stage_out.reserve((size_t)n * 4))) return rc;
+    hipStream_t st = h->own_stream;
+    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n_in * 8, hipMemcpyHostToDevice, st));
+    rc = grhip_xlating_demod_work_device(h, noutput_items, h->stage_in.p, h->stage_out.p, st);
+    if (rc < 0) return rc;
+    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    GRHIP_HIP(hipStreamSynchronize(st));
+    return noutput_items;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// digital_kernels.h -- launchers for clock_recovery_mm_ff, binary_slicer_fb,
+// correlate_access_code_bb (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace grhip {
+
+// device-resident state of one digital_clock_recovery_mm_ff instance
+// (gr-digital/include/digital_clock_recovery_mm_ff.h:77-92)
+struct MMState {
+    float mu, omega, min_omega, omega_mid, max_omega;
+    float gain_omega, gain_mu, last_sample, omega_relative_limit;
+    int pad;
+};
+
+// one wave per stream; stream s reads in + s*in_stride, writes out + s*out_stride,
+// state[s], counts[2*s] = produced, counts[2*s+1] = consumed.
+// n_in_ptr (optional, device int per stream with stride n_in_ptr_stride): when
+// non-null the number of input items is min(ninput_items, n_in_ptr[s*stride]).
+int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items, const float *in,
+              long long in_stride, float *out, long long out_stride, int *counts,
+              const float *mmse_rev, hipStream_t st);
+
+int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipStream_t st);
+
+// device-resident state of one digital_correlate_access_code_bb instance
+struct CorrState {
+    unsigned long long data_reg, flag_reg;
+};
+struct CorrParams {
+    unsigned long long access_code, mask;
+    unsigned threshold;
+    unsigned len;
+};
+// in_bytes != nullptr: byte input (LSB used); else in_soft: float input sliced
+// with x >= 0 (binary_slicer fused in front).  n_ptr (optional): per-stream item
+// count on the device (n = min(n, n_ptr[s*n_ptr_stride])).
+int launch_correlate(const CorrParams &p, CorrState *state, int n_streams, const unsigned char *in_bytes,
+                     const float *in_soft, long long in_stride, unsigned char *out, long long out_stride,
+                     long long n, const int *n_ptr, int n_ptr_stride, hipStream_t st);
+
+}  // namespace grhip

@@ -1,0 +1,289 @@
+// digital_kernels.hip -- gfx950 kernels for the gr-digital tail of the DMR chain:
+//   digital_clock_recovery_mm_ff (+ gri_mmse_fir_interpolator),
+//   digital_binary_slicer_fb, digital_correlate_access_code_bb.
+#include "digital_kernels.h"
+
+#include "device_math.h"
+#include "grhip_internal.h"
+
+namespace grhip {
+
+// ===========================================================================
+// Mueller & Mueller clock recovery
+//   gr-digital/lib/digital_clock_recovery_mm_ff.cc:104-139
+//   filter/gri_mmse_fir_interpolator.cc:61-71 (8-tap gr_fir_fff, 129 phases)
+// The loop is serial and data dependent: one wavefront per stream.
+// All 64 lanes stage the next MM_CH input floats into LDS with coalesced loads;
+// lane 0 then walks the symbols inside that window out of LDS (interpolator
+// taps also in LDS), so the dependent chain never waits on HBM.  Throughput
+// comes from running many independent streams (one workgroup each).
+// Every float operation below is a single unfused IEEE op in the reference's
+// order: bit-exact.
+// ===========================================================================
+constexpr int MM_CH = 4096;
+constexpr int MM_NTAPS = 8;
+constexpr int MM_NSTEPS = 128;
+
+__device__ __forceinline__ float mm_slice(float x) { return x < 0 ? -1.0f : 1.0f; }
+
+__global__ void __launch_bounds__(64)
+mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, const float *__restrict__ in,
+          long long in_stride, float *__restrict__ out, long long out_stride, int *__restrict__ counts,
+          const float *__restrict__ mmse_rev)
+{
+    __shared__ float s_in[MM_CH];
+    __shared__ float s_taps[MM_NTAPS * (MM_NSTEPS + 1)];
+    __shared__ int s_ctl[4];
+
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const float *__restrict__ x = in + (long long)s * in_stride;
+    float *__restrict__ y = out + (long long)s * out_stride;
+
+    for (int i = lane; i < MM_NTAPS * (MM_NSTEPS + 1); i += 64) s_taps[i] = mmse_rev[i];
+
+    MMState st = state[s];
+    int ii = 0, oo = 0;
+    const int ni = ninput_items - MM_NTAPS;          // .cc:113
+    int done = !(oo < noutput_items && ii < ni);
+
+    while (!done) {
+        const int base = ii;
+        for (int i = lane; i < MM_CH; i += 64) {
+            long long g = (long long)base + i;
+            s_in[i] = (g >= 0 && g < ninput_items) ? x[g] : 0.f;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            const int lim = base + MM_CH - MM_NTAPS;
+            float mu = st.mu, omega = st.omega, last = st.last_sample;
+            const float omega_mid = st.omega_mid, gain_omega = st.gain_omega, gain_mu = st.gain_mu;
+            const float rel = st.omega_relative_limit;
+            while (oo < noutput_items && ii < ni && ii <= lim && ii >= base) {
+                // interpolate(&in[ii], d_mu): imu = (int) rint(mu * NSTEPS)
+                int imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
+                imu = imu < 0 ? 0 : (imu > MM_NSTEPS ? MM_NSTEPS : imu);
+                const float *xw = &s_in[ii - base];
+                const float *tp = &s_taps[imu];
+                // gr_fir_fff_generic::filter, ntaps = 8, N_UNROLL = 4
+                float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+                acc0 += tp[0 * (MM_NSTEPS + 1)] * xw[0];
+                acc1 += tp[1 * (MM_NSTEPS + 1)] * xw[1];
+                acc2 += tp[2 * (MM_NSTEPS + 1)] * xw[2];
+                acc3 += tp[3 * (MM_NSTEPS + 1)] * xw[3];
+                acc0 += tp[4 * (MM_NSTEPS + 1)] * xw[4];
+                acc1 += tp[5 * (MM_NSTEPS + 1)] * xw[5];
+                acc2 += tp[6 * (MM_NSTEPS + 1)] * xw[6];
+                acc3 += tp[7 * (MM_NSTEPS + 1)] * xw[7];
+                const float o = (acc0 + acc1 + acc2 + acc3);
+                y[oo] = o;
+                const float mm_val = mm_slice(last) * o - mm_slice(o) * last;     // .cc:120
+                last = o;
+                omega = omega + gain_omega * mm_val;                              // .cc:123
+                omega = omega_mid + branchless_clip(omega - omega_mid, rel);      // .cc:124
+                mu = mu + omega + gain_mu * mm_val;                               // .cc:125
+                const float fl = __builtin_floorf(mu);
+                ii += (int)fl;                                                    // .cc:127
+                mu = mu - fl;                                                     // .cc:128
+                oo++;
+            }
+            st.mu = mu; st.omega = omega; st.last_sample = last;
+            int d = !(oo < noutput_items && ii < ni);
+            if (ii < 0) d = 1;     // the reference would read before its buffer here
+            s_ctl[0] = ii; s_ctl[1] = oo; s_ctl[2] = d;
+        }
+        __syncthreads();
+        ii = s_ctl[0]; oo = s_ctl[1]; done = s_ctl[2];
+        __syncthreads();
+    }
+    if (lane == 0) {
+        state[s] = st;
+        counts[2 * s + 0] = oo;
+        counts[2 * s + 1] = ii;          // consume_each(ii)
+    }
+}
+
+int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items, const float *in,
+              long long in_stride, float *out, long long out_stride, int *counts, const float *mmse_rev,
+              hipStream_t st)
+{
+    if (n_streams <= 0) return GRHIP_OK;
+    hipLaunchKernelGGL(mm_kernel, dim3(n_streams), dim3(64), 0, st, state, noutput_items, ninput_items, in,
+                       in_stride, out, out_stride, counts, mmse_rev);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+// ===========================================================================
+// binary slicer (gr-digital/lib/digital_binary_slicer_fb.cc:54-56)
+// ===========================================================================
+__global__ void __launch_bounds__(256)
+slicer_kernel(const float *__restrict__ in, unsigned char *__restrict__ out, long long n)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (in[i] >= 0) ? 1 : 0;
+}
+
+int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipStream_t st)
+{
+    if (n <= 0) return GRHIP_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slicer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+// ===========================================================================
+// correlate_access_code_bb (gr-digital/lib/digital_correlate_access_code_bb.cc:95-130)
+// Closed form of the shift-register loop: with registers
+// (data_reg, flag_reg) at the start of the call,
+//   out[i] bit0 = bit i-64 of the input stream            (data_reg for i < 64)
+//   out[i] bit1 = flag_reg bit (63-i) for i < 64,  OR
+//                 [popcount((W_k ^ code) & mask) <= thr],  k = i - len >= 0
+//   W_k = the 64 stream bits before position k, oldest at the MSB.
+// A 256-lane workgroup owns CORR_TB outputs: it packs the input bits it needs
+// into 64-bit words in LDS with wave ballots (coalesced byte / float loads),
+// then every lane emits 8 output bytes with one 8-byte store.  HBM-bound:
+// 1 B (or 4 B when the slicer is fused) in + 1 B out per item.
+// ===========================================================================
+constexpr int CORR_TB = 2048;
+constexpr int CORR_WORDS = CORR_TB / 64 + 2;
+
+__device__ __forceinline__ unsigned long long corr_word(const unsigned long long *P, long long w,
+                                                        long long wlo, unsigned long long data_reg)
+{
+    // packed word w (stream bits 64w .. 64w+63, first bit at the MSB)
+    if (w == -1) return data_reg;
+    if (w < -1) return 0ull;
+    return P[w - wlo];
+}
+
+__global__ void __launch_bounds__(256)
+corr_kernel(CorrParams p, const CorrState *__restrict__ state_in, const unsigned char *__restrict__ in_bytes,
+            const float *__restrict__ in_soft, long long in_stride, unsigned char *__restrict__ out,
+            long long out_stride, long long n_arg, const int *__restrict__ n_ptr, int n_ptr_stride)
+{
+    __shared__ unsigned long long P[CORR_WORDS];
+    const int s = blockIdx.y, t = threadIdx.x;
+    long long n = n_arg;
+    if (n_ptr) { long long m = n_ptr[(long long)s * n_ptr_stride]; n = m < n ? m : n; }
+    const long long i0 = (long long)blockIdx.x * CORR_TB;
+    if (i0 >= n) return;
+    const unsigned char *__restrict__ xb = in_bytes ? in_bytes + (long long)s * in_stride : nullptr;
+    const float *__restrict__ xf = in_soft ? in_soft + (long long)s * in_stride : nullptr;
+    const CorrState st = state_in[s];
+
+    // words i0/64 - 2 .. i0/64 + CORR_TB/64 - 1
+    const long long wlo = i0 / 64 - 2;
+    for (int wi = t >> 6; wi < CORR_WORDS; wi += 4) {
+        long long w = wlo + wi;
+        long long idx = w * 64 + (t & 63);
+        int bit = 0;
+        if (idx >= 0 && idx < n) bit = xb ? (xb[idx] & 1) : (xf[idx] >= 0 ? 1 : 0);
+        unsigned long long m = __ballot(bit);            // lane l -> bit l
+        if ((t & 63) == 0) P[wi] = __brevll(m);          // first item at the MSB
+    }
+    __syncthreads();
+
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long i = i0 + 8 * t + j;
+        unsigned o = 0;
+        if (i < n) {
+            // bit 0: stream bit i-64
+            long long b = i - 64;
+            long long w = b >> 6;                          // floor division (arithmetic shift)
+            int r = (int)(b & 63);
+            o |= (unsigned)((corr_word(P, w, wlo, st.data_reg) >> (63 - r)) & 1ull);
+            // bit 1: flags already in flight at call start
+            if (i < 64) o |= (unsigned)((st.flag_reg >> (63 - i)) & 1ull) << 1;
+            // bit 1: flag computed len items ago
+            long long k = i - (long long)p.len;
+            if (k >= 0 && p.len > 0) {
+                long long wk = k >> 6;
+                int rk = (int)(k & 63);
+                unsigned long long hi = corr_word(P, wk - 1, wlo, st.data_reg);
+                unsigned long long W = hi;
+                if (rk) W = (hi << rk) | (corr_word(P, wk, wlo, st.data_reg) >> (64 - rk));
+                unsigned nwrong = (unsigned)__popcll((W ^ p.access_code) & p.mask);
+                if (nwrong <= p.threshold) o |= 2u;
+            }
+        }
+        packed |= (unsigned long long)o << (8 * j);
+    }
+    unsigned char *__restrict__ y = out + (long long)s * out_stride;
+    const long long o0 = i0 + 8 * t;
+    if (o0 + 8 <= n && ((((uintptr_t)(y + o0)) & 7) == 0)) {
+        *reinterpret_cast<unsigned long long *>(y + o0) = packed;
+    } else {
+        for (int j = 0; j < 8; ++j)
+            if (o0 + j < n) y[o0 + j] = (unsigned char)(packed >> (8 * j));
+    }
+}
+
+// registers after n items (one 64-lane workgroup per stream)
+__global__ void __launch_bounds__(64)
+corr_tail_kernel(CorrParams p, CorrState *__restrict__ state, const unsigned char *__restrict__ in_bytes,
+                 const float *__restrict__ in_soft, long long in_stride, long long n_arg,
+                 const int *__restrict__ n_ptr, int n_ptr_stride)
+{
+    const int s = blockIdx.x, t = threadIdx.x;
+    long long n = n_arg;
+    if (n_ptr) { long long m = n_ptr[(long long)s * n_ptr_stride]; n = m < n ? m : n; }
+    if (n <= 0) return;
+    const unsigned char *__restrict__ xb = in_bytes ? in_bytes + (long long)s * in_stride : nullptr;
+    const float *__restrict__ xf = in_soft ? in_soft + (long long)s * in_stride : nullptr;
+    const CorrState st = state[s];
+    auto bit_at = [&](long long idx) -> unsigned long long {
+        if (idx >= n) return 0ull;
+        if (idx >= 0) return xb ? (unsigned long long)(xb[idx] & 1) : (xf[idx] >= 0 ? 1ull : 0ull);
+        long long back = -1 - idx;                  // in[-1] is data_reg bit 0
+        return back < 64 ? (st.data_reg >> back) & 1ull : 0ull;
+    };
+    // lane t evaluates the flag of position k = n - 1 - t (for t < len), which sits at
+    // flag_reg bit (64 - len) + t after n items.
+    unsigned long long contrib = 0;
+    if (t < (int)p.len) {
+        long long k = n - 1 - t;
+        if (k >= 0) {
+            unsigned long long W = 0;
+            for (int j = 0; j < 64; ++j) W = (W << 1) | bit_at(k - 64 + j);
+            unsigned nwrong = (unsigned)__popcll((W ^ p.access_code) & p.mask);
+            if (nwrong <= p.threshold) contrib = 1ull << (64 - p.len + t);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        unsigned lo = (unsigned)contrib, hi = (unsigned)(contrib >> 32);
+        lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o);
+        contrib = ((unsigned long long)hi << 32) | lo;
+    }
+    if (t == 0) {
+        unsigned long long d = 0;
+        for (int j = 0; j < 64; ++j) d = (d << 1) | bit_at(n - 64 + j);
+        unsigned long long f = (n < 64) ? (st.flag_reg << n) : 0ull;
+        CorrState ns;
+        ns.data_reg = d;
+        ns.flag_reg = f | contrib;
+        state[s] = ns;
+    }
+}
+
+int launch_correlate(const CorrParams &p, CorrState *state, int n_streams, const unsigned char *in_bytes,
+                     const float *in_soft, long long in_stride, unsigned char *out, long long out_stride,
+                     long long n, const int *n_ptr, int n_ptr_stride, hipStream_t st)
+{
+    if (n <= 0 || n_streams <= 0) return GRHIP_OK;
+    dim3 grid((unsigned)((n + CORR_TB - 1) / CORR_TB), (unsigned)n_streams);
+    hipLaunchKernelGGL(corr_kernel, grid, dim3(256), 0, st, p, (const CorrState *)state, in_bytes, in_soft,
+                       in_stride, out, out_stride, n, n_ptr, n_ptr_stride);
+    GRHIP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(corr_tail_kernel, dim3(n_streams), dim3(64), 0, st, p, state, in_bytes, in_soft,
+                       in_stride, n, n_ptr, n_ptr_stride);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+}  // namespace grhip

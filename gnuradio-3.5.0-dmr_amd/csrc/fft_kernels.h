@@ -1,0 +1,29 @@
+// fft_kernels.h -- launchers for gr_fft_vcc and gr_pfb_channelizer_ccf (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace grhip {
+
+// One workgroup per vector, radix-4/radix-2 Stockham in LDS.
+// twiddle: device float2[N], twiddle[k] = exp(-2*pi*i*k/N) (forward sign; the
+// backward transform conjugates on the fly).  window: device float[N] or null.
+// shift semantics as gr_fft_vcc_fftw::work (general/gr_fft_vcc_fftw.cc:68-96).
+int launch_fft(int N, int forward, int shift, const float *window, const float2 *twiddle,
+               const float2 *in, float2 *out, long long nvec, hipStream_t st);
+bool fft_size_supported(int N);
+
+struct PfbArgs {
+    int M;              // numchans
+    int tpf;            // taps per filter
+    int rate_ratio;     // (int)rintf(M / oversample_rate)
+    const float *ftaps; // [M][tpf] reversed taps (as gr_fir_ccf stores them)
+    const int *idxlut;  // [M]
+    const float2 *dft;  // [M] exp(+2*pi*i*m/M)
+    const float2 *in;   // stream j at in + j*stride, item 0 = oldest history item
+    long long stride;
+    float2 *out;        // [nout][M]
+    long long nout;
+};
+int launch_pfb(const PfbArgs &a, hipStream_t st);
+
+}  // namespace grhip

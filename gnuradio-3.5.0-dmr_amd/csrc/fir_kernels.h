@@ -1,0 +1,53 @@
+// fir_kernels.h -- launchers of the FIR-family kernels (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace grhip {
+
+enum FirKind { FIR_FFF = 0, FIR_CCF = 1, FIR_CCC = 2 };
+
+// ---- (A) generic-order kernel: bit-exact gr_fir_XXX_generic -----------------
+// taps_rev: device, d_taps order (reversed forward taps); complex interleaved
+// for CCC.  in: device, item 0 = input[0] of output 0.  Any decimation.
+// epilogue: if gtab != nullptr (complex kinds) out[n] = rotate(out[n], gtab[n])
+// with the reference's unfused complex product (gr_rotator.h:43).
+int launch_fir_generic(FirKind kind, const float *taps_rev, int ntaps, const void *in, void *out,
+                       long long n_out, int decim, const float2 *gtab, hipStream_t st);
+
+// ---- (B) tiled fast kernel (complex data) ------------------------------------
+struct FirTiledArgs {
+    const float2 *x;        // stream 0; item 0 = input[0] of output 0
+    long long x_stride;     // items between streams
+    long long n_in;         // items at index >= n_in read as 0
+    long long n_lo;         // items at index <  n_lo read as 0 (never dereferenced)
+    const float *hp;        // phase-major padded taps [D][Tq] (x2 floats if complex)
+    int Tq;                 // taps per phase, multiple of R
+    long long n_out;        // outputs per stream
+    const float2 *wtab;     // PREMIX: W[u], u in [0,(NT+Tq)*D)
+    const float2 *vtab;     // PREMIX: V[j'], j' in [0,NT]
+    const float2 *gtab;     // EPI>=1: rotator phase per output of this call (stream-independent)
+    float2 *y_out;          // EPI 0/1
+    long long y_stride;
+    float *d_out;           // EPI 2
+    long long d_stride;
+    float gain;             // EPI 2
+    const float2 *y_prev;   // EPI 2: [n_streams] y[-1] carried in from the previous call
+    float2 *y_last;         // EPI 2: [n_streams] receives the last y of this call (distinct buffer)
+    const float *atan_tab;  // EPI 2
+    int vec_store;          // 1 if output rows are 16-byte aligned
+};
+
+enum { EPI_NONE = 0, EPI_ROTATE = 1, EPI_ROTATE_DEMOD = 2 };
+
+// returns GRHIP_OK or <0 ; `decim` must be one of tiled_supported_decim().
+bool tiled_supported(int decim, int ntaps_padded_per_phase);
+int tiled_R();                      // outputs per lane
+int tiled_NT();                     // outputs per workgroup
+int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiledArgs &a,
+                     int n_streams, hipStream_t st);
+
+// standalone quadrature demod: in has 1 history item in front
+int launch_quad_demod(const float2 *in, float *out, long long n_out, float gain,
+                      const float *atan_tab, hipStream_t st);
+
+}  // namespace grhip

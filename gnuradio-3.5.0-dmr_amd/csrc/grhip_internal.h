@@ -1,0 +1,75 @@
+// grhip_internal.h -- shared plumbing of libgrhip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/grhip.h"
+
+namespace grhip {
+
+// ---- thread-local error detail -------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define GRHIP_HIP(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return ::grhip::fail(e__ == hipErrorOutOfMemory ? GRHIP_ENOMEM : GRHIP_ERUNTIME, \
+                                 "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),    \
+                                 __FILE__, __LINE__);                                       \
+    } while (0)
+
+// ---- device buffer that only ever grows -----------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return GRHIP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        GRHIP_HIP(hipMalloc(&p, want));
+        cap = want;
+        return GRHIP_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// ---- base of every block handle -------------------------------------------
+struct HandleBase {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    std::mutex setter_mutex;   // setters vs. the work thread
+    DevBuf stage_in, stage_out;
+
+    int init_device(int dev);
+    void destroy_base();
+    hipStream_t pick(void *stream) const { return stream ? (hipStream_t)stream : own_stream; }
+    int bind() const;          // hipSetDevice for the calling thread
+};
+
+int default_mode();
+
+// shared read-only device tables (per device, created on first use)
+struct DeviceTables {
+    float *atan_tab = nullptr;       // 257 floats   (gr_fast_atan2f table)
+    float *mmse_rev = nullptr;       // [8][129] floats, tap-major, reversed taps
+};
+int get_device_tables(int device, const DeviceTables **out);
+
+}  // namespace grhip

@@ -1,0 +1,335 @@
+/*
+ * grhip.h -- C ABI of libgrhip.so: the MI355X (gfx950) implementation of the
+ * GNU Radio 3.5.0 DMR demodulation hot path.
+ *
+ * Plain C types only; no exceptions cross this boundary.  Every entry point
+ * returns an int status (GRHIP_OK or a negative GRHIP_E*), except the *_work
+ * calls which return the number of items produced (>= 0) like
+ * gr_block::general_work (gnuradio-core/src/lib/runtime/gr_block.h:107-127)
+ * or a negative GRHIP_E*.
+ *
+ * Each block type mirrors one reference block.  The citation on every group
+ * names the reference interface it replaces (paths relative to the reference
+ * tree).  Semantics common to all blocks:
+ *
+ *  - *_work(h, noutput_items, in, out): HOST pointers, same contract as
+ *    gr_sync_block / gr_sync_decimator ::work: `in` points at the oldest
+ *    history item, i.e. in[0 .. history-2] are items the block saw before
+ *    (runtime/gr_block.h:76-84, runtime/gr_sync_block.cc:46-50), and
+ *    noutput_items*decimation + history - 1 items are readable
+ *    (runtime/gr_sync_decimator.cc:46-50).  The call copies to the device,
+ *    runs the kernels on the handle's stream, copies back and returns when
+ *    the output is in `out`.
+ *  - *_work_device(..., stream): same contract with DEVICE pointers; enqueues
+ *    on `stream` (a hipStream_t passed as void*; NULL = the handle's own
+ *    stream) and returns without synchronising.
+ *  - setters latch a new value that takes effect at the next work call, which
+ *    then returns 0 items once, exactly as the reference does
+ *    (filter/gr_fir_filter_XXX.cc.t:74-79,
+ *     filter/gr_freq_xlating_fir_filter_XXX.cc.t:109-114).
+ *  - one handle is driven by one thread at a time (thread-per-block scheduler,
+ *    runtime/gr_scheduler_tpb.cc:70-77); setters may be called from another
+ *    thread.
+ *  - complex items are interleaved float (re, im) == gr_complex
+ *    (runtime/gr_complex.h:26).
+ */
+#ifndef INCLUDED_GRHIP_H
+#define INCLUDED_GRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define GRHIP_API __attribute__((visibility("default")))
+#else
+#define GRHIP_API
+#endif
+
+/* ---- status codes -------------------------------------------------------
+ * The C++ block wrappers rethrow them as the exception type the reference
+ * throws for the same precondition. */
+#define GRHIP_OK 0
+#define GRHIP_EINVAL (-1)   /* std::invalid_argument */
+#define GRHIP_ERANGE (-2)   /* std::out_of_range     */
+#define GRHIP_ERUNTIME (-3) /* std::runtime_error (HIP call failed) */
+#define GRHIP_ENOMEM (-4)   /* std::bad_alloc        */
+#define GRHIP_ENODEV (-5)   /* no usable gfx950 device / HIP runtime */
+
+GRHIP_API const char *grhip_strerror(int status);
+/* thread-local detail of the last failing call on this thread ("" if none) */
+GRHIP_API const char *grhip_last_error(void);
+GRHIP_API int grhip_device_count(int *count);
+/* blocks until everything enqueued on the handle-independent default work has
+ * finished on `device` (hipDeviceSynchronize) */
+GRHIP_API int grhip_device_synchronize(int device);
+GRHIP_API const char *grhip_version(void);
+
+/* numeric mode of the FIR-type blocks (process-wide default, may be
+ * overridden per handle):
+ *   GRHIP_MODE_FAST    tiled kernels, FMA, own summation order
+ *                      (within 1e-5 relative of the reference)
+ *   GRHIP_MODE_GENERIC summation order and unfused arithmetic of
+ *                      gr_fir_XXX_generic (filter/gr_fir_XXX_generic.cc.t:30-79):
+ *                      bit-exact against the generic reference path */
+#define GRHIP_MODE_FAST 0
+#define GRHIP_MODE_GENERIC 1
+GRHIP_API int grhip_set_default_mode(int mode);
+GRHIP_API int grhip_get_default_mode(void);
+
+/* ======================================================================
+ * gr_fir_filter_{ccf,fff,ccc}
+ *   replaces gr_make_fir_filter_XXX(int decimation, const std::vector<TAP>&)
+ *   filter/gr_fir_filter_XXX.h.t:36-66, filter/gr_fir_filter_XXX.cc.t:37-88
+ * kind: "ccf" | "fff" | "ccc".  taps in forward order (complex taps
+ * interleaved, ntaps counts taps not floats).  history = ntaps.
+ * ====================================================================== */
+typedef struct grhip_fir_filter grhip_fir_filter;
+GRHIP_API int grhip_fir_filter_create(grhip_fir_filter **h, const char *kind, int decimation,
+                                      const float *taps, size_t ntaps, int device);
+GRHIP_API void grhip_fir_filter_destroy(grhip_fir_filter *h);
+GRHIP_API int grhip_fir_filter_set_taps(grhip_fir_filter *h, const float *taps, size_t ntaps);
+GRHIP_API int grhip_fir_filter_set_mode(grhip_fir_filter *h, int mode);
+GRHIP_API int grhip_fir_filter_history(const grhip_fir_filter *h);
+GRHIP_API int grhip_fir_filter_decimation(const grhip_fir_filter *h);
+GRHIP_API int grhip_fir_filter_work(grhip_fir_filter *h, int noutput_items, const void *in, void *out);
+GRHIP_API int grhip_fir_filter_work_device(grhip_fir_filter *h, int noutput_items, const void *d_in,
+                                           void *d_out, void *stream);
+/* kernel-level seam: gr_fir_XXX::filterN / filterNdec
+ * (filter/gr_fir_XXX.h.t:87-100): output[i] = filter(&input[i*decimate]);
+ * ignores latched updates, never returns 0-because-updated. */
+GRHIP_API int grhip_fir_filterNdec(grhip_fir_filter *h, void *output, const void *input,
+                                   unsigned long n, unsigned decimate);
+
+/* ======================================================================
+ * gr_freq_xlating_fir_filter_ccc
+ *   replaces gr_make_freq_xlating_fir_filter_ccc(int decimation,
+ *       const std::vector<gr_complex>& taps, double center_freq, double sampling_freq)
+ *   filter/gr_freq_xlating_fir_filter_XXX.h.t:64-99, .cc.t:38-123
+ * history = ntaps.  Carries the gr_rotator state (filter/gr_rotator.h:29-52)
+ * across calls.
+ * ====================================================================== */
+typedef struct grhip_freq_xlating_fir_filter_ccc grhip_freq_xlating_fir_filter_ccc;
+GRHIP_API int grhip_freq_xlating_fir_filter_ccc_create(grhip_freq_xlating_fir_filter_ccc **h,
+                                                       int decimation, const float *taps,
+                                                       size_t ntaps, double center_freq,
+                                                       double sampling_freq, int device);
+GRHIP_API void grhip_freq_xlating_fir_filter_ccc_destroy(grhip_freq_xlating_fir_filter_ccc *h);
+GRHIP_API int grhip_freq_xlating_fir_filter_ccc_set_center_freq(grhip_freq_xlating_fir_filter_ccc *h,
+                                                               double center_freq);
+GRHIP_API int grhip_freq_xlating_fir_filter_ccc_set_taps(grhip_freq_xlating_fir_filter_ccc *h,
+                                                        const float *taps, size_t ntaps);
+GRHIP_API int grhip_freq_xlating_fir_filter_ccc_set_mode(grhip_freq_xlating_fir_filter_ccc *h, int mode);
+GRHIP_API int grhip_freq_xlating_fir_filter_ccc_history(const grhip_freq_xlating_fir_filter_ccc *h);
+GRHIP_API int grhip_freq_xlating_fir_filter_ccc_work(grhip_freq_xlating_fir_filter_ccc *h,
+                                                     int noutput_items, const void *in, void *out);
+GRHIP_API int grhip_freq_xlating_fir_filter_ccc_work_device(grhip_freq_xlating_fir_filter_ccc *h,
+                                                            int noutput_items, const void *d_in,
+                                                            void *d_out, void *stream);
+/* restart the stream (rotator phase 1, counter 0) without rebuilding taps:
+ * what constructing a fresh block for the next capture does. */
+GRHIP_API int grhip_freq_xlating_fir_filter_ccc_reset(grhip_freq_xlating_fir_filter_ccc *h);
+
+/* ======================================================================
+ * gr_quadrature_demod_cf
+ *   replaces gr_make_quadrature_demod_cf(float gain)
+ *   general/gr_quadrature_demod_cf.h, general/gr_quadrature_demod_cf.cc:31-62
+ *   (+ gr_fast_atan2f, general/gr_fast_atan2f.cc:125-198).  history = 2.
+ * ====================================================================== */
+typedef struct grhip_quadrature_demod_cf grhip_quadrature_demod_cf;
+GRHIP_API int grhip_quadrature_demod_cf_create(grhip_quadrature_demod_cf **h, float gain, int device);
+GRHIP_API void grhip_quadrature_demod_cf_destroy(grhip_quadrature_demod_cf *h);
+GRHIP_API int grhip_quadrature_demod_cf_work(grhip_quadrature_demod_cf *h, int noutput_items,
+                                             const void *in, void *out);
+GRHIP_API int grhip_quadrature_demod_cf_work_device(grhip_quadrature_demod_cf *h, int noutput_items,
+                                                    const void *d_in, void *d_out, void *stream);
+
+/* ======================================================================
+ * Fused hier block: freq_xlating_fir_filter_ccc -> quadrature_demod_cf
+ * (what tb.connect(xlating, demod) builds; one kernel, the xlating output
+ * never goes to HBM).  Same arguments as the two blocks.  `in` has the
+ * xlating history (ntaps-1) in front; out is float.  Carries the rotator and
+ * the demodulator's previous sample across calls.
+ * ====================================================================== */
+typedef struct grhip_xlating_demod grhip_xlating_demod;
+GRHIP_API int grhip_xlating_demod_create(grhip_xlating_demod **h, int decimation, const float *taps,
+                                         size_t ntaps, double center_freq, double sampling_freq,
+                                         float gain, int device);
+GRHIP_API void grhip_xlating_demod_destroy(grhip_xlating_demod *h);
+GRHIP_API int grhip_xlating_demod_set_mode(grhip_xlating_demod *h, int mode);
+GRHIP_API int grhip_xlating_demod_reset(grhip_xlating_demod *h);
+GRHIP_API int grhip_xlating_demod_history(const grhip_xlating_demod *h);
+GRHIP_API int grhip_xlating_demod_work(grhip_xlating_demod *h, int noutput_items, const void *in,
+                                       void *out);
+GRHIP_API int grhip_xlating_demod_work_device(grhip_xlating_demod *h, int noutput_items,
+                                              const void *d_in, void *d_out, void *stream);
+
+/* ======================================================================
+ * digital_clock_recovery_mm_ff
+ *   replaces digital_make_clock_recovery_mm_ff(float omega, float gain_omega,
+ *       float mu, float gain_mu, float omega_relative_limit)
+ *   gr-digital/include/digital_clock_recovery_mm_ff.h:44-92,
+ *   gr-digital/lib/digital_clock_recovery_mm_ff.cc:37-139
+ * general_work contract: consumes *consumed items (consume_each), returns
+ * items produced; uses at most ninput_items - 8 inputs (.cc:113).
+ * GRHIP_ERANGE if omega < 1 or a gain is negative (.cc:58-61).
+ * ====================================================================== */
+typedef struct grhip_clock_recovery_mm_ff grhip_clock_recovery_mm_ff;
+GRHIP_API int grhip_clock_recovery_mm_ff_create(grhip_clock_recovery_mm_ff **h, float omega,
+                                                float gain_omega, float mu, float gain_mu,
+                                                float omega_relative_limit, int device);
+GRHIP_API void grhip_clock_recovery_mm_ff_destroy(grhip_clock_recovery_mm_ff *h);
+GRHIP_API int grhip_clock_recovery_mm_ff_forecast(const grhip_clock_recovery_mm_ff *h, int noutput_items);
+GRHIP_API int grhip_clock_recovery_mm_ff_general_work(grhip_clock_recovery_mm_ff *h, int noutput_items,
+                                                      int ninput_items, const float *in, float *out,
+                                                      int *consumed);
+/* device form: produced/consumed are written to d_counts[0], d_counts[1]
+ * (device int[2]) so a following kernel can read them without a host sync */
+GRHIP_API int grhip_clock_recovery_mm_ff_general_work_device(grhip_clock_recovery_mm_ff *h,
+                                                             int noutput_items, int ninput_items,
+                                                             const float *d_in, float *d_out,
+                                                             int *d_counts, void *stream);
+GRHIP_API float grhip_clock_recovery_mm_ff_mu(grhip_clock_recovery_mm_ff *h);
+GRHIP_API float grhip_clock_recovery_mm_ff_omega(grhip_clock_recovery_mm_ff *h);
+GRHIP_API float grhip_clock_recovery_mm_ff_gain_mu(grhip_clock_recovery_mm_ff *h);
+GRHIP_API float grhip_clock_recovery_mm_ff_gain_omega(grhip_clock_recovery_mm_ff *h);
+GRHIP_API int grhip_clock_recovery_mm_ff_set_gain_mu(grhip_clock_recovery_mm_ff *h, float v);
+GRHIP_API int grhip_clock_recovery_mm_ff_set_gain_omega(grhip_clock_recovery_mm_ff *h, float v);
+GRHIP_API int grhip_clock_recovery_mm_ff_set_mu(grhip_clock_recovery_mm_ff *h, float v);
+GRHIP_API int grhip_clock_recovery_mm_ff_set_omega(grhip_clock_recovery_mm_ff *h, float v);
+
+/* ======================================================================
+ * digital_binary_slicer_fb
+ *   replaces digital_make_binary_slicer_fb()
+ *   gr-digital/lib/digital_binary_slicer_fb.cc:31-59
+ * ====================================================================== */
+typedef struct grhip_binary_slicer_fb grhip_binary_slicer_fb;
+GRHIP_API int grhip_binary_slicer_fb_create(grhip_binary_slicer_fb **h, int device);
+GRHIP_API void grhip_binary_slicer_fb_destroy(grhip_binary_slicer_fb *h);
+GRHIP_API int grhip_binary_slicer_fb_work(grhip_binary_slicer_fb *h, int noutput_items,
+                                          const float *in, unsigned char *out);
+GRHIP_API int grhip_binary_slicer_fb_work_device(grhip_binary_slicer_fb *h, int noutput_items,
+                                                 const float *d_in, unsigned char *d_out, void *stream);
+
+/* ======================================================================
+ * digital_correlate_access_code_bb
+ *   replaces digital_make_correlate_access_code_bb(const std::string&
+ *       access_code, int threshold)
+ *   gr-digital/include/digital_correlate_access_code_bb.h,
+ *   gr-digital/lib/digital_correlate_access_code_bb.cc:37-133
+ * access_code: string of '0'/'1' characters (only the LSB of each byte is
+ * used, .cc:80); GRHIP_ERANGE if longer than 64 (.cc:54-57).
+ * ====================================================================== */
+typedef struct grhip_correlate_access_code_bb grhip_correlate_access_code_bb;
+GRHIP_API int grhip_correlate_access_code_bb_create(grhip_correlate_access_code_bb **h,
+                                                    const char *access_code, size_t len,
+                                                    int threshold, int device);
+GRHIP_API void grhip_correlate_access_code_bb_destroy(grhip_correlate_access_code_bb *h);
+GRHIP_API int grhip_correlate_access_code_bb_set_access_code(grhip_correlate_access_code_bb *h,
+                                                             const char *access_code, size_t len);
+GRHIP_API int grhip_correlate_access_code_bb_work(grhip_correlate_access_code_bb *h, int noutput_items,
+                                                  const unsigned char *in, unsigned char *out);
+GRHIP_API int grhip_correlate_access_code_bb_work_device(grhip_correlate_access_code_bb *h,
+                                                         int noutput_items, const unsigned char *d_in,
+                                                         unsigned char *d_out, void *stream);
+
+/* ======================================================================
+ * gr_fft_vcc
+ *   replaces gr_make_fft_vcc(int fft_size, bool forward,
+ *       const std::vector<float>& window, bool shift)
+ *   general/gr_fft_vcc.h:41-59, general/gr_fft_vcc.cc:34-64,
+ *   general/gr_fft_vcc_fftw.cc:39-103 (FFTW3f c2c, unnormalised)
+ * items are vectors of fft_size complex.  window: NULL/0 or fft_size floats.
+ * GRHIP_ERANGE if fft_size <= 0 (general/gri_fft.cc:104-105);
+ * GRHIP_EINVAL if fft_size is not a power of two <= 65536 (device limit of
+ * this implementation).
+ * ====================================================================== */
+typedef struct grhip_fft_vcc grhip_fft_vcc;
+GRHIP_API int grhip_fft_vcc_create(grhip_fft_vcc **h, int fft_size, int forward, const float *window,
+                                   size_t window_len, int shift, int device);
+GRHIP_API void grhip_fft_vcc_destroy(grhip_fft_vcc *h);
+/* returns 1 if accepted, 0 if the length is wrong (gr_fft_vcc::set_window) */
+GRHIP_API int grhip_fft_vcc_set_window(grhip_fft_vcc *h, const float *window, size_t window_len);
+GRHIP_API int grhip_fft_vcc_work(grhip_fft_vcc *h, int noutput_items, const void *in, void *out);
+GRHIP_API int grhip_fft_vcc_work_device(grhip_fft_vcc *h, int noutput_items, const void *d_in,
+                                        void *d_out, void *stream);
+
+/* ======================================================================
+ * gr_pfb_channelizer_ccf
+ *   replaces gr_make_pfb_channelizer_ccf(unsigned numchans,
+ *       const std::vector<float>& taps, float oversample_rate)
+ *   filter/gr_pfb_channelizer_ccf.h:115-178, filter/gr_pfb_channelizer_ccf.cc:36-200
+ * numchans input streams, one output stream of numchans-complex vectors.
+ * history = taps_per_filter + 1 on every input.  GRHIP_EINVAL if
+ * numchans/oversample_rate is not an integer (.cc:57-60).
+ * general_work: ins[j] points at stream j including history; returns
+ * noutput_items, *consumed = items to consume on every input.
+ * ====================================================================== */
+typedef struct grhip_pfb_channelizer_ccf grhip_pfb_channelizer_ccf;
+GRHIP_API int grhip_pfb_channelizer_ccf_create(grhip_pfb_channelizer_ccf **h, unsigned numchans,
+                                               const float *taps, size_t ntaps, float oversample_rate,
+                                               int device);
+GRHIP_API void grhip_pfb_channelizer_ccf_destroy(grhip_pfb_channelizer_ccf *h);
+GRHIP_API int grhip_pfb_channelizer_ccf_set_taps(grhip_pfb_channelizer_ccf *h, const float *taps,
+                                                 size_t ntaps);
+GRHIP_API int grhip_pfb_channelizer_ccf_history(const grhip_pfb_channelizer_ccf *h);
+GRHIP_API int grhip_pfb_channelizer_ccf_output_multiple(const grhip_pfb_channelizer_ccf *h);
+GRHIP_API int grhip_pfb_channelizer_ccf_general_work(grhip_pfb_channelizer_ccf *h, int noutput_items,
+                                                     const void *const *ins, void *out, int *consumed);
+/* device form: the numchans streams live in ONE device buffer, stream j at
+ * d_in + j*stream_stride_items complex items */
+GRHIP_API int grhip_pfb_channelizer_ccf_general_work_device(grhip_pfb_channelizer_ccf *h,
+                                                            int noutput_items, const void *d_in,
+                                                            size_t stream_stride_items, void *d_out,
+                                                            void *stream);
+
+/* ======================================================================
+ * Full DMR chain as one device-resident pipeline (hier block):
+ *   freq_xlating_fir_filter_ccc -> quadrature_demod_cf ->
+ *   clock_recovery_mm_ff -> binary_slicer_fb -> correlate_access_code_bb
+ * for n_streams independent captures with identical parameters (SURVEY 8(e):
+ * streams are independent units; this is the multi-stream batch that fills
+ * the device for the serial M&M stage).  Each stream starts from fresh block
+ * state on every run() (a capture is processed whole).
+ * ====================================================================== */
+typedef struct grhip_dmr_chain grhip_dmr_chain;
+typedef struct grhip_dmr_chain_params {
+    int decimation;
+    const float *taps; /* complex prototype taps, interleaved */
+    size_t ntaps;
+    double center_freq, sampling_freq;
+    float demod_gain;
+    float omega, gain_omega, mu, gain_mu, omega_relative_limit;
+    const char *access_code;
+    size_t access_code_len;
+    int threshold;
+} grhip_dmr_chain_params;
+GRHIP_API int grhip_dmr_chain_create(grhip_dmr_chain **h, const grhip_dmr_chain_params *p,
+                                     int n_streams, size_t max_samples_per_stream, int device);
+GRHIP_API void grhip_dmr_chain_destroy(grhip_dmr_chain *h);
+/* d_in: n_streams captures of n_samples complex each, stream s at
+ * d_in + s*stream_stride_items (NO history in front: the chain supplies the
+ * zeros a fresh flowgraph would).  d_bits: n_streams * bits_stride bytes;
+ * d_nbits: n_streams ints (symbols produced per stream). */
+GRHIP_API int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_samples,
+                                         size_t stream_stride_items, unsigned char *d_bits,
+                                         size_t bits_stride, int *d_nbits, void *stream);
+/* intermediate products of the last run (device pointers owned by the handle):
+ * which: 0 demod floats, 1 M&M soft symbols; *stride receives the per-stream
+ * stride in items */
+GRHIP_API int grhip_dmr_chain_intermediate(grhip_dmr_chain *h, int which, void **d_ptr, size_t *stride);
+
+/* ---- small device-memory helpers for hosts without a HIP binding -------- */
+GRHIP_API int grhip_malloc(void **d_ptr, size_t bytes, int device);
+GRHIP_API int grhip_free(void *d_ptr);
+GRHIP_API int grhip_memcpy_h2d(void *d_dst, const void *src, size_t bytes);
+GRHIP_API int grhip_memcpy_d2h(void *dst, const void *d_src, size_t bytes);
+GRHIP_API int grhip_stream_synchronize(void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INCLUDED_GRHIP_H */

@@ -1,0 +1,273 @@
+"""-m gpu parity tests of the FIR family through the C ABI (ctypes) against the
+CPU oracle.  Tolerances: GENERIC mode bit-exact; FAST mode 1e-5 relative
+(BASELINE.json north_star), measured as ||y-ref||inf / ||ref||inf and, where
+|ref| is not tiny, per element (filter/qa_gr_fir_ccf.cc:151-152 style)."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, rel_err_max
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rand_c(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+
+
+@pytest.mark.parametrize("kind", ["fff", "ccf", "ccc"])
+@pytest.mark.parametrize("ntaps", [1, 2, 7, 8, 64, 255, 256])
+@pytest.mark.parametrize("decim", [1, 4])
+def test_fir_generic_mode_bit_exact(gpu, po, kind, ntaps, decim):
+    rng = np.random.default_rng(ntaps * 10 + decim)
+    n = 3001
+    nin = (n - 1) * decim + ntaps
+    if kind == "fff":
+        x = rng.uniform(-1, 1, nin).astype(np.float32)
+        taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+        blk = gpu.fir_filter_fff(decim, taps)
+        ref = po.fir_fff(taps, x, n, decim)
+    elif kind == "ccf":
+        x = _rand_c(rng, nin)
+        taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+        blk = gpu.fir_filter_ccf(decim, taps)
+        ref = po.fir_ccf(taps, x, n, decim)
+    else:
+        x = _rand_c(rng, nin)
+        taps = _rand_c(rng, ntaps)
+        blk = gpu.fir_filter_ccc(decim, taps)
+        ref = po.fir_ccc(taps, x, n, decim)
+    blk.set_mode(gpu.MODE_GENERIC)
+    assert blk.history() == ntaps
+    got = blk.work(n, x)
+    assert bits_equal(got, ref)
+
+
+@pytest.mark.parametrize("kind", ["ccf", "ccc"])
+@pytest.mark.parametrize("ntaps,decim", [(1, 1), (3, 1), (64, 1), (65, 2), (256, 4), (255, 4), (256, 1), (31, 8), (40, 3)])
+def test_fir_fast_mode_tolerance(gpu, po, kind, ntaps, decim):
+    rng = np.random.default_rng(1000 + ntaps * 10 + decim)
+    n = 5003           # not a multiple of the tile: exercises the ragged tail
+    nin = (n - 1) * decim + ntaps
+    x = _rand_c(rng, nin)
+    if kind == "ccf":
+        taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+        blk = gpu.fir_filter_ccf(decim, taps)
+        ref = po.fir_ccf(taps, x, n, decim)
+        bound = np.abs(taps).sum()
+    else:
+        taps = _rand_c(rng, ntaps)
+        blk = gpu.fir_filter_ccc(decim, taps)
+        ref = po.fir_ccc(taps, x, n, decim)
+        bound = np.abs(taps).sum() * np.sqrt(2)
+    blk.set_mode(gpu.MODE_FAST)
+    got = blk.work(n, x)
+    assert got.shape == ref.shape
+    # random taps: outputs have heavy cancellation, so bound the error by the
+    # worst-case output magnitude ||taps||_1 * ||x||_inf
+    assert np.abs(got - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3 * bound)
+
+
+def test_fir_integer_data_exact_all_modes(gpu, po):
+    """integer-valued data: every summation order is exact
+    (filter/qa_gr_fir_ccf.cc:103-159 uses the same trick)"""
+    rng = np.random.default_rng(7)
+    for ntaps in range(0, 10):
+        for n in (1, 2, 17):
+            x = (rng.integers(-8, 8, (n + ntaps, 2))).astype(np.float32).view(np.complex64).reshape(-1)
+            taps = rng.integers(-8, 8, ntaps).astype(np.float32)
+            ref = po.fir_ccf(taps, x, n, 1)
+            for mode in (gpu.MODE_FAST, gpu.MODE_GENERIC):
+                blk = gpu.fir_filter_ccf(1, taps)
+                blk.set_mode(mode)
+                got = blk.work(n, x)
+                assert np.array_equal(got, ref), (ntaps, n, mode)
+
+
+def test_fir_fff_known_vectors(gpu):
+    """filter/qa_gr_fir_fff.cc:58-76"""
+    inp = np.array([234, -4, 23, -56, 45, 98, -23, -7], np.float32)
+    blk = gpu.fir_filter_fff(1, [-3])
+    assert np.array_equal(blk.work(8, inp), np.array([-702, 12, -69, 168, -135, -294, 69, 21], np.float32))
+    blk = gpu.fir_filter_fff(1, [-4, 5])
+    assert np.array_equal(blk.work(7, inp), np.array([1186, -112, 339, -460, -167, 582, -87], np.float32))
+    # filterN / filterNdec seam
+    assert np.array_equal(blk.filterNdec(inp, 4, 2), np.array([1186, 339, -167, -87], np.float32))
+
+
+def test_fir_set_taps_returns_zero_once(gpu, po):
+    """filter/gr_fir_filter_XXX.cc.t:74-79"""
+    rng = np.random.default_rng(3)
+    x = _rand_c(rng, 2000)
+    blk = gpu.fir_filter_ccf(1, [1.0, 2.0])
+    blk.set_mode(gpu.MODE_GENERIC)
+    y0 = blk.work(100, x)
+    assert len(y0) == 100
+    blk.set_taps([0.5, 0.25, 0.125])
+    assert len(blk.work(100, x)) == 0          # update consumed, nothing produced
+    assert blk.history() == 3
+    y1 = blk.work(100, x)
+    assert bits_equal(y1, po.fir_ccf([0.5, 0.25, 0.125], x, 100, 1))
+
+
+def test_fir_through_scheduler_shim_cfg1(gpu, po, wl):
+    """config 1: gr_fir_filter_ccf 64-tap low-pass on a complex vector through the
+    chunked sync-block runner (history zeros, 4096-item calls)."""
+    n = 200_000
+    x = wl.uniform_complex(n)
+    taps = wl.lowpass_taps(64, 0.1, 1.0)
+    blk = gpu.fir_filter_ccf(1, taps)
+    got = gpu.run_sync_block(blk, x, chunk=4096)
+    ref = po.fir_ccf(taps, wl.with_history(x, 63), n, 1)
+    assert rel_err_max(got, ref) <= TOL
+    blk2 = gpu.fir_filter_ccf(1, taps)
+    blk2.set_mode(gpu.MODE_GENERIC)
+    assert bits_equal(gpu.run_sync_block(blk2, x, chunk=4096), ref)
+
+
+# ---------------------------------------------------------------------------
+# freq_xlating_fir_filter_ccc
+# ---------------------------------------------------------------------------
+def test_xlating_generic_bit_exact_and_rotator_carry(gpu, po, wl):
+    c = wl.CFG2
+    n = 120_000
+    x = wl.fsk4_capture(n)
+    proto = wl.cfg2_proto_taps()
+    nout = n // c["decim"]
+    xin = wl.with_history(x, len(proto) - 1)
+    ref = po.Xlating(c["decim"], proto, c["center_freq"], c["fs"]).work(xin, nout)
+    blk = gpu.freq_xlating_fir_filter_ccc(c["decim"], proto, c["center_freq"], c["fs"])
+    blk.set_mode(gpu.MODE_GENERIC)
+    assert blk.history() == 256
+    # one big call
+    assert bits_equal(blk.work(nout, xin), ref)
+    # chunked calls: rotator phase/counter carried across calls (gr_rotator.h:40-50,
+    # renormalisation every 512 outputs crosses chunk boundaries)
+    blk.reset()
+    got = gpu.run_sync_block(blk, x, chunk=1000)
+    assert bits_equal(got, ref)
+
+
+@pytest.mark.parametrize("complex_proto", [False, True])
+def test_xlating_fast_tolerance(gpu, po, wl, complex_proto):
+    c = wl.CFG2
+    n = 400_000
+    x = wl.fsk4_capture(n, stream_id=1)
+    proto = wl.cfg2_proto_taps()
+    if complex_proto:   # forces the complex-tap tiled path (no pre-mix)
+        proto = (proto * np.exp(1j * 0.01 * np.arange(len(proto)))).astype(np.complex64)
+    nout = n // c["decim"]
+    xin = wl.with_history(x, len(proto) - 1)
+    ref = po.Xlating(c["decim"], proto, c["center_freq"], c["fs"]).work(xin, nout)
+    blk = gpu.freq_xlating_fir_filter_ccc(c["decim"], proto, c["center_freq"], c["fs"])
+    blk.set_mode(gpu.MODE_FAST)
+    got = blk.work(nout, xin)
+    assert rel_err_max(got, ref) <= TOL
+    # per element where the reference is not tiny (pass-band signal, |y| ~ 1)
+    m = np.abs(ref) > 0.1 * np.abs(ref).max()
+    assert (np.abs(got - ref)[m] / np.abs(ref)[m]).max() <= TOL
+    # chunked: same stream in 4096-output calls must continue seamlessly
+    blk.reset()
+    got2 = gpu.run_sync_block(blk, x, chunk=4096)
+    assert rel_err_max(got2, ref) <= TOL
+
+
+def test_xlating_set_center_freq_keeps_phase(gpu, po, wl):
+    """set_center_freq -> next work returns 0, then new composite taps and
+    increment with the rotator phase carried on (.cc.t:86-114)"""
+    c = wl.CFG2
+    n = 40_000
+    x = wl.fsk4_capture(n, stream_id=2)
+    proto = wl.cfg2_proto_taps()
+    blk = gpu.freq_xlating_fir_filter_ccc(4, proto, c["center_freq"], c["fs"])
+    blk.set_mode(gpu.MODE_GENERIC)
+    xin = wl.with_history(x, 255)
+    a = blk.work(2000, xin)
+    blk.set_center_freq(1.0e6)
+    assert len(blk.work(10, xin)) == 0
+    b = blk.work(3000, xin[8000:])
+    # oracle: same sequence by hand
+    o = po.Xlating(4, proto, c["center_freq"], c["fs"])
+    ra = o.work(xin, 2000)
+    ph, inc, cnt = o.rot()
+    o2 = po.Xlating(4, proto, 1.0e6, c["fs"])
+    ph2, inc2, _ = o2.rot()
+    phases = np.empty(3000, np.complex64)
+    pr, pi = np.float32(ph.real), np.float32(ph.imag)
+    ir, ii = np.float32(inc2.real), np.float32(inc2.imag)
+    k = cnt
+    for i in range(3000):
+        phases[i] = complex(pr, pi)
+        k += 1
+        ac, bd, ad, bc = np.float32(pr * ir), np.float32(pi * ii), np.float32(pr * ii), np.float32(pi * ir)
+        pr, pi = np.float32(ac - bd), np.float32(ad + bc)
+        if k % 512 == 0:
+            a_ = np.float32(np.hypot(np.float64(pr), np.float64(pi)))
+            pr, pi = np.float32(pr / a_), np.float32(pi / a_)
+    fir = po.fir_ccc(o2.ctaps()[::-1].copy(), xin[8000:], 3000, 4)
+    fr, fi = fir.real.astype(np.float32), fir.imag.astype(np.float32)
+    cr, ci = phases.real.astype(np.float32), phases.imag.astype(np.float32)
+    rb = ((fr * cr).astype(np.float32) - (fi * ci).astype(np.float32)) + 1j * ((fr * ci).astype(np.float32) + (fi * cr).astype(np.float32))
+    assert bits_equal(a, ra)
+    assert rel_err_max(b, rb.astype(np.complex64)) <= 2e-7   # hypot rounding path differs in numpy; ~1 ulp
+
+
+# ---------------------------------------------------------------------------
+# quadrature_demod_cf and the fused hier block
+# ---------------------------------------------------------------------------
+def test_quad_demod_bit_exact(gpu, po):
+    rng = np.random.default_rng(11)
+    n = 100_003
+    x = _rand_c(rng, n + 1)
+    # axes, zeros, equal magnitudes: all octant/shortcut branches of gr_fast_atan2f
+    x[10] = 0; x[11] = 0; x[20] = 1; x[21] = 1j; x[22] = -1; x[23] = -1j; x[24] = 1 + 1j; x[25] = 1e-4 + 1j
+    blk = gpu.quadrature_demod_cf(4.9)
+    got = blk.work(n, x)
+    ref = po.quad_demod_cf(4.9, x, n)
+    assert bits_equal(got, ref)
+
+
+def test_fused_xlating_demod_cfg2(gpu, po, wl):
+    c = wl.CFG2
+    n = 1_000_000
+    x = wl.fsk4_capture(n, stream_id=3)
+    proto = wl.cfg2_proto_taps()
+    nout = n // c["decim"]
+    ref = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], x)
+    xin = wl.with_history(x, 255)
+    blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
+    got = blk.work(nout, xin)
+    assert rel_err_max(got, ref) <= TOL
+    # generic mode: FIR+rotator bit exact, demod bit exact => whole chain bit exact
+    blk.reset(); blk.set_mode(gpu.MODE_GENERIC)
+    assert bits_equal(blk.work(nout, xin), ref)
+    # chunked fast: demodulator's previous sample carried across calls
+    blk.reset(); blk.set_mode(gpu.MODE_FAST)
+    got2 = gpu.run_sync_block(blk, x, chunk=8192)
+    assert rel_err_max(got2, ref) <= TOL
+
+
+def test_unfused_pipeline_equals_fused(gpu, po, wl):
+    """tb.connect(xlating, demod) as two blocks vs the fused hier block"""
+    c = wl.CFG2
+    n = 200_000
+    x = wl.fsk4_capture(n, stream_id=4)
+    proto = wl.cfg2_proto_taps()
+    nout = n // 4
+    xl = gpu.freq_xlating_fir_filter_ccc(4, proto, c["center_freq"], c["fs"])
+    qd = gpu.quadrature_demod_cf(c["demod_gain"])
+    y = xl.work(nout, wl.with_history(x, 255))
+    d = qd.work(nout, wl.with_history(y, 1))
+    fused = gpu.xlating_demod(4, proto, c["center_freq"], c["fs"], c["demod_gain"]).work(nout, wl.with_history(x, 255))
+    # only the tile-boundary predecessor differs (tree-order sum): well inside tolerance
+    assert rel_err_max(d, fused) <= 2e-6
+
+
+def test_errors_and_edges(gpu):
+    with pytest.raises(gpu.GrhipError):
+        gpu.fir_filter_ccf(0, [1.0])
+    blk = gpu.fir_filter_ccf(1, [])
+    assert blk.history() == 1
+    assert len(blk.work(0, np.zeros(0, np.complex64))) == 0
+    out = blk.work(5, np.ones(5, np.complex64))          # zero taps -> zeros
+    assert np.array_equal(out, np.zeros(5, np.complex64))
