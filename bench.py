@@ -155,13 +155,15 @@ def main():
     out = torch.empty((B, ((nout + 63) // 64) * 64), dtype=torch.float32, device=dev)
 
     blk = g.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], device=local_rank)
-    stream = torch.cuda.current_stream()
+    # a real (non-null) stream: the kernels, and the events that time them, all go here
+    stream = torch.cuda.Stream(device=dev)
 
     def step():
         for b in range(B):
             blk.reset()
             blk.work_device(nout, buf[b], out[b], stream)
 
+    torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()

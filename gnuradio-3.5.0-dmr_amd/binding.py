@@ -36,6 +36,15 @@ def lib():
     global _LIB
     if _LIB is None:
         p = lib_path()
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64
+        # with the same SONAME.  If torch is going to be used for device memory /
+        # streams / torch.distributed, it must be the copy that gets loaded first,
+        # otherwise torch later reports "No HIP GPUs are available".
+        if os.environ.get("GRHIP_NO_TORCH_PRELOAD") is None:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         if not os.path.exists(p):
             raise ImportError("libgrhip.so not built (%s): run __graft_entry__.build(); "
                               "there is no CPU fallback" % p)
@@ -591,6 +600,9 @@ class dmr_chain(_Block):
                                              C.c_size_t, C.c_int]
         _check(L.grhip_dmr_chain_create(C.byref(self._h), C.byref(p), self.n_streams, int(max_samples),
                                         int(device)))
+
+    def set_mode(self, mode):
+        _check(lib().grhip_dmr_chain_set_mode(self._h, int(mode)))
 
     def run_device(self, d_in, n_samples, stream_stride_items, d_bits, bits_stride, d_nbits, stream=None):
         L = lib()

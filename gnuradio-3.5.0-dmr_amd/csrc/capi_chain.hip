@@ -27,8 +27,9 @@ struct grhip_dmr_chain : HandleBase {
     int S = 1;
     size_t max_samples = 0, max_out = 0;
     const DeviceTables *tabs = nullptr;
-    DevBuf d_demod, d_soft, d_mm, d_mm_init, d_counts, d_ystate, d_corr;
+    DevBuf d_demod, d_soft, d_mm, d_mm_init, d_counts, d_ystate, d_corr, d_scratch;
     size_t out_stride = 0;
+    int mode = GRHIP_MODE_FAST;
 };
 
 extern "C" {
@@ -91,7 +92,7 @@ void grhip_dmr_chain_destroy(grhip_dmr_chain *h)
     (void)hipSetDevice(h->device);
     h->core.release();
     h->d_demod.release(); h->d_soft.release(); h->d_mm.release(); h->d_mm_init.release();
-    h->d_counts.release(); h->d_ystate.release(); h->d_corr.release();
+    h->d_counts.release(); h->d_ystate.release(); h->d_corr.release(); h->d_scratch.release();
     h->destroy_base();
     delete h;
 }
@@ -120,10 +121,26 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
     const long long hist = h->core.ntaps > 0 ? h->core.ntaps - 1 : 0;
     const float2 *x = (const float2 *)d_in - hist;
     float2 *ys = h->d_ystate.as<float2>();
-    rc = h->core.run(GRHIP_MODE_FAST, x, hist + (long long)n_samples, n_out, nullptr, h->d_demod.as<float>(),
-                     h->gain, ys, ys + S, h->tabs->atan_tab, st, h->S, (long long)stream_stride_items, hist,
-                     (long long)h->out_stride);
-    if (rc) return rc;
+    if (h->mode == GRHIP_MODE_FAST) {
+        rc = h->core.run(GRHIP_MODE_FAST, x, hist + (long long)n_samples, n_out, nullptr, h->d_demod.as<float>(),
+                         h->gain, ys, ys + S, h->tabs->atan_tab, st, h->S, (long long)stream_stride_items, hist,
+                         (long long)h->out_stride);
+        if (rc) return rc;
+    } else {
+        // generic order: explicit zero history in a scratch row, one stream at a time
+        rc = h->d_scratch.reserve((size_t)(hist + (long long)n_samples) * sizeof(float2));
+        if (rc) return rc;
+        for (size_t s = 0; s < S; ++s) {
+            GRHIP_HIP(hipMemsetAsync(h->d_scratch.p, 0, (size_t)hist * sizeof(float2), st));
+            GRHIP_HIP(hipMemcpyAsync(h->d_scratch.as<float2>() + hist, (const float2 *)d_in + s * stream_stride_items,
+                                     n_samples * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            h->core.reset();
+            rc = h->core.run(GRHIP_MODE_GENERIC, h->d_scratch.as<float2>(), hist + (long long)n_samples, n_out,
+                             nullptr, h->d_demod.as<float>() + s * h->out_stride, h->gain, ys + s, ys + S + s,
+                             h->tabs->atan_tab, st);
+            if (rc) return rc;
+        }
+    }
 
     // 2) M&M clock recovery, one wavefront per stream
     rc = launch_mm(h->d_mm.as<MMState>(), h->S, (int)n_out, (int)n_out, h->d_demod.as<float>(),
@@ -138,6 +155,13 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
     if (rc) return rc;
     GRHIP_HIP(hipMemcpy2DAsync(d_nbits, sizeof(int), h->d_counts.p, 2 * sizeof(int), sizeof(int), S,
                                hipMemcpyDeviceToDevice, st));
+    return GRHIP_OK;
+}
+
+int grhip_dmr_chain_set_mode(grhip_dmr_chain *h, int mode)
+{
+    if (!h || (mode != GRHIP_MODE_FAST && mode != GRHIP_MODE_GENERIC)) return fail(GRHIP_EINVAL, "bad mode");
+    h->mode = mode;
     return GRHIP_OK;
 }
 

@@ -18,6 +18,8 @@
 //      Epilogues: rotator multiply (xlating) and fused quadrature demod.
 #include "fir_kernels.h"
 
+#include <cstdlib>
+
 #include "device_math.h"
 #include "grhip_internal.h"
 
@@ -185,7 +187,9 @@ __global__ void __launch_bounds__(TILED_THREADS, 2) fir_tiled_kernel(const FirTi
         for (int u = -off + 2 * t; u < Lu; u += 2 * TILED_THREADS) {
             const long long g = g0 + u;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g >= a.n_lo && g + 1 < a.n_in) {
+            if (a.ablate & 1) {
+                v = make_float4(1.f, 0.5f, 0.25f, 0.125f);
+            } else if (g >= a.n_lo && g + 1 < a.n_in) {
                 v = *reinterpret_cast<const float4 *>(x + g);
             } else {
                 if (g >= a.n_lo && g < a.n_in) { float2 e = x[g]; v.x = e.x; v.y = e.y; }
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(TILED_THREADS, 2) fir_tiled_kernel(const FirTi
     for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
 
     const int lane_base = (t + 1) * R + (t + 1);   // slot of mm = (t+1)R
-    for (int p = 0; p < D; ++p) {
+    for (int p = 0; p < ((a.ablate & 2) ? 0 : D); ++p) {
         const float2 *xp = xs + p * PS + lane_base;
         float2 w[R];
 #pragma unroll
@@ -318,7 +322,7 @@ __global__ void __launch_bounds__(TILED_THREADS, 2) fir_tiled_kernel(const FirTi
         float d[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            d[r] = quad_demod_one(acc[r], prev, a.gain, a.atan_tab);
+            d[r] = (a.ablate & 4) ? acc[r].x + prev.y : quad_demod_one(acc[r], prev, a.gain, a.atan_tab);
             prev = acc[r];
         }
         float *__restrict__ o = a.d_out + (long long)s * a.d_stride;
@@ -379,11 +383,23 @@ static int launch_tiled_d(bool ctaps, bool premix, int epi, const FirTiledArgs &
     return launch_tiled_inst<D, false, false, EPI_NONE>(a, ns, st);
 }
 
+static int launch_fir_tiled_impl(int decim, bool ctaps, bool premix, int epi, const FirTiledArgs &a,
+                                 int n_streams, hipStream_t st);
+
 int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiledArgs &a, int n_streams,
                      hipStream_t st)
 {
     if (a.n_out <= 0 || n_streams <= 0) return GRHIP_OK;
     if (!tiled_supported(decim, a.Tq)) return fail(GRHIP_EINVAL, "tiled FIR: unsupported shape");
+    static int ablate = -1;
+    if (ablate < 0) { const char *e = getenv("GRHIP_ABLATE"); ablate = e ? atoi(e) : 0; }
+    if (ablate) { FirTiledArgs b = a; b.ablate = ablate; return launch_fir_tiled_impl(decim, ctaps, premix, epi, b, n_streams, st); }
+    return launch_fir_tiled_impl(decim, ctaps, premix, epi, a, n_streams, st);
+}
+
+static int launch_fir_tiled_impl(int decim, bool ctaps, bool premix, int epi, const FirTiledArgs &a,
+                                 int n_streams, hipStream_t st)
+{
     switch (decim) {
     case 1: return launch_tiled_d<1>(ctaps, premix, epi, a, n_streams, st);
     case 2: return launch_tiled_d<2>(ctaps, premix, epi, a, n_streams, st);

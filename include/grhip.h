@@ -310,6 +310,10 @@ typedef struct grhip_dmr_chain_params {
 GRHIP_API int grhip_dmr_chain_create(grhip_dmr_chain **h, const grhip_dmr_chain_params *p,
                                      int n_streams, size_t max_samples_per_stream, int device);
 GRHIP_API void grhip_dmr_chain_destroy(grhip_dmr_chain *h);
+/* GRHIP_MODE_GENERIC runs the xlating FIR in gr_fir_ccc_generic order (one
+ * stream at a time): the whole chain is then bit-exact against the reference's
+ * generic path, symbols and bit decisions included. */
+GRHIP_API int grhip_dmr_chain_set_mode(grhip_dmr_chain *h, int mode);
 /* d_in: n_streams captures of n_samples complex each, stream s at
  * d_in + s*stream_stride_items (NO history in front: the chain supplies the
  * zeros a fresh flowgraph would).  d_bits: n_streams * bits_stride bytes;

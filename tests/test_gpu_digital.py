@@ -1,0 +1,145 @@
+"""-m gpu parity tests: clock_recovery_mm_ff (bit-exact), binary_slicer_fb and
+correlate_access_code_bb (bit-exact, integer work) through the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def qa():
+    with open(os.path.join(GOLD, "ref_qa_vectors.json")) as f:
+        return json.load(f)
+
+
+def _fsk_soft(rng, nsym, sps=10, noise=0.15):
+    x = np.repeat(rng.choice([-3.0, -1.0, 1.0, 3.0], nsym), sps)
+    x = np.convolve(x, np.ones(4) / 4, mode="same")
+    return (x + rng.normal(0, noise, len(x))).astype(np.float32)
+
+
+def test_mm_reference_qa(gpu, qa):
+    """gr-digital/python/qa_clock_recovery_mm.py:70-102,140-172 on the GPU path"""
+    m = qa["mm"]["test02"]
+    cr = gpu.clock_recovery_mm_ff(m["omega"], m["gain_omega"], m["mu"], m["gain_mu"], m["omega_rel_lim"])
+    out, _ = cr.general_work(1000, np.ones(100, np.float32))
+    np.testing.assert_allclose(out[-30:], m["expected_last30"], atol=0.5 * 10 ** -m["places"])
+    m = qa["mm"]["test04"]
+    cr = gpu.clock_recovery_mm_ff(m["omega"], m["gain_omega"], m["mu"], m["gain_mu"], m["omega_rel_lim"])
+    out, _ = cr.general_work(100000, np.array(1000 * [1, 1, -1, -1], np.float32))
+    assert np.allclose(np.abs(out[-100:]), 1.31, atol=0.1)
+
+
+@pytest.mark.parametrize("omega,gm", [(10.0, 0.175), (2.0, 0.05), (4.3, 0.3)])
+def test_mm_bit_exact_whole_stream(gpu, po, omega, gm):
+    rng = np.random.default_rng(int(omega * 10))
+    x = _fsk_soft(rng, 12000, sps=int(round(omega)))
+    go = 0.25 * gm * gm
+    ref, st = po.chain_mm(omega, go, 0.5, gm, 0.005, x)
+    cr = gpu.clock_recovery_mm_ff(omega, go, 0.5, gm, 0.005)
+    out, consumed = cr.general_work(len(x), x)
+    assert bits_equal(out, ref)
+    assert consumed == st["consumed"]
+    assert np.float32(cr.mu()) == st["mu"] and np.float32(cr.omega()) == st["omega"]
+    # the window refill boundary (4096 floats) is crossed many times here
+    assert len(x) > 4 * 4096
+
+
+def test_mm_chunked_like_scheduler(gpu, po, wl):
+    c4 = wl.CFG4
+    rng = np.random.default_rng(21)
+    x = _fsk_soft(rng, 5000)
+    ref, _ = po.chain_mm(c4["omega"], c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], x)
+    cr = gpu.clock_recovery_mm_ff(c4["omega"], c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"])
+    assert cr.forecast(100) == int(np.ceil(100 * c4["omega"] + 8))
+    outs, pos = [], 0
+    while True:
+        o, used = cr.general_work(300, x[pos:pos + 4096])
+        if len(o) == 0:
+            break
+        outs.append(o); pos += used
+    assert bits_equal(np.concatenate(outs), ref)
+
+
+def test_mm_errors_and_setters(gpu, po):
+    with pytest.raises(gpu.GrhipError) as e:
+        gpu.clock_recovery_mm_ff(0.5, 0.01, 0.5, 0.01, 0.001)
+    assert e.value.code == -2          # std::out_of_range
+    with pytest.raises(gpu.GrhipError):
+        gpu.clock_recovery_mm_ff(2, 0.01, 0.5, -0.01, 0.001)
+    cr = gpu.clock_recovery_mm_ff(2, 0.01, 0.5, 0.02, 0.001)
+    assert abs(cr.gain_mu() - 0.02) < 1e-9 and abs(cr.gain_omega() - 0.01) < 1e-9
+    cr.set_omega(3.0); cr.set_mu(0.25); cr.set_gain_mu(0.05); cr.set_gain_omega(0.002)
+    o = po.ClockRecoveryMM(3.0, 0.002, 0.25, 0.05, 0.001)
+    x = np.sin(np.arange(3000) * 2 * np.pi / 6.0).astype(np.float32)
+    ref, _ = o.general_work(2000, x)
+    out, _ = cr.general_work(2000, x)
+    assert bits_equal(out, ref)
+    # empty / too-short input: nothing produced, nothing consumed
+    out, used = cr.general_work(10, np.zeros(5, np.float32))
+    assert len(out) == 0 and used == 0
+
+
+def test_binary_slicer(gpu, po):
+    rng = np.random.default_rng(2)
+    x = rng.normal(0, 1, 100_001).astype(np.float32)
+    x[:4] = [0.0, -0.0, 1e-45, -1e-45]
+    assert np.array_equal(gpu.binary_slicer_fb().work(len(x), x), po.binary_slicer_fb(x))
+
+
+def test_correlator_reference_qa(gpu, qa):
+    c = qa["corr"]
+    t1 = c["test_001"]
+    out = gpu.correlate_access_code_bb(t1["code"], t1["threshold"]).work(len(t1["src"]), np.array(t1["src"], np.uint8))
+    assert out.tolist() == t1["expected"]
+    code = []
+    for b in c["default_access_code_bytes"]:
+        code += [(b >> i) & 1 for i in range(8)]
+    src = code + c["test_002"]["tail"] + [0] * 64
+    exp = [0] * 64 + code + c["test_002"]["expected_tail"]
+    out = gpu.correlate_access_code_bb("".join(str(v) for v in code), 0).work(len(src), np.array(src, np.uint8))
+    assert out.tolist() == exp
+    with pytest.raises(gpu.GrhipError) as e:
+        gpu.correlate_access_code_bb("1" * 65, 0)
+    assert e.value.code == -2
+
+
+@pytest.mark.parametrize("L,thr", [(1, 0), (4, 0), (48, 0), (48, 4), (48, 12), (63, 3), (64, 0), (64, 7)])
+def test_correlator_random_bit_exact(gpu, po, L, thr):
+    rng = np.random.default_rng(L * 100 + thr)
+    code = rng.integers(0, 2, L)
+    n = 70_001                      # ragged: not a multiple of the 2048-item tile
+    bits = rng.integers(0, 256, n).astype(np.uint8)      # only the LSB counts (.cc:124)
+    for pos in (0, 5, 2040, 2047, 2048, 4000, 65000, n - L):
+        seg = code.copy()
+        flip = rng.integers(0, L, min(thr, L))
+        seg[flip] ^= 1
+        bits[pos:pos + L] = (bits[pos:pos + L] & 0xFE) | seg
+    s = "".join(map(str, code))
+    ref = po.CorrelateAccessCode(s, thr).work(bits)
+    got = gpu.correlate_access_code_bb(s, thr).work(n, bits)
+    assert np.array_equal(got, ref)
+    assert (ref & 2).any() or L > 60
+
+
+def test_correlator_state_across_calls(gpu, po):
+    """d_data_reg / d_flag_reg carried across work() calls, at every alignment"""
+    rng = np.random.default_rng(77)
+    code = rng.integers(0, 2, 48)
+    bits = rng.integers(0, 2, 30_000).astype(np.uint8)
+    for pos in range(100, 29_000, 997):
+        bits[pos:pos + 48] = code
+    s = "".join(map(str, code))
+    ref = po.CorrelateAccessCode(s, 2).work(bits)
+    blk = gpu.correlate_access_code_bb(s, 2)
+    outs, pos = [], 0
+    for n in [1, 2, 3, 63, 64, 65, 47, 48, 49, 1000, 2047, 2048, 2049, 4096, 10]:
+        outs.append(blk.work(n, bits[pos:pos + n])); pos += n
+    outs.append(blk.work(len(bits) - pos, bits[pos:]))
+    assert np.array_equal(np.concatenate(outs), ref)

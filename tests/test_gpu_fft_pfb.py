@@ -1,0 +1,144 @@
+"""-m gpu parity tests: gr_fft_vcc and gr_pfb_channelizer_ccf.
+FFT tolerance: the reference's own (qa_fft.py: rel 4e-4) on its 32-point
+vectors; against the float64 DFT oracle 1e-6*log2(N) of ||X||inf (FFTW3f is a
+third-party float transform whose codelet order is not restatable: "parity
+unpinned" beyond the reference's 32-point vectors)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err_max
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rc(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+
+
+def test_fft_reference_qa_vectors(gpu):
+    with open(os.path.join(GOLD, "ref_qa_vectors.json")) as f:
+        v = json.load(f)["fft32"]
+    p = v["primes"]
+    src = np.array([complex(p[2 * i], p[2 * i + 1]) for i in range(32)], np.complex64)
+    exp = np.array([complex(a, b) for a, b in v["forward_expected"]], np.complex64)
+    got = gpu.fft_vcc(32, True, [], False).work(1, src)
+    assert np.all(np.abs(got - exp) <= v["abs_eps"] + v["rel_eps"] * np.abs(exp))
+    back = gpu.fft_vcc(32, False, [], False).work(1, (exp / 32).astype(np.complex64))
+    assert np.all(np.abs(back - src) <= v["abs_eps"] + v["rel_eps"] * np.abs(src))
+
+
+@pytest.mark.parametrize("N", [1, 2, 4, 8, 16, 64, 128, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("forward", [True, False])
+def test_fft_sizes_vs_oracle(gpu, po, N, forward):
+    rng = np.random.default_rng(N + int(forward))
+    nvec = 5
+    x = _rc(rng, N * nvec)
+    ref = po.fft_vcc(N, forward, None, False, x)
+    got = gpu.fft_vcc(N, forward, [], False).work(nvec, x)
+    assert rel_err_max(got, ref) <= 1e-6 * max(np.log2(N), 1)
+
+
+@pytest.mark.parametrize("forward,shift,win", [(True, True, False), (False, True, False), (True, False, True),
+                                               (False, True, True), (True, True, True)])
+def test_fft_window_and_shift(gpu, po, forward, shift, win):
+    rng = np.random.default_rng(5)
+    N, nvec = 256, 7
+    x = _rc(rng, N * nvec)
+    w = np.hamming(N).astype(np.float32) if win else None
+    ref = po.fft_vcc(N, forward, w, shift, x)
+    blk = gpu.fft_vcc(N, forward, w if win else [], shift)
+    assert rel_err_max(blk.work(nvec, x), ref) <= 1e-5
+    # set_window: wrong length refused, right length accepted (gr_fft_vcc.cc:55-64)
+    assert blk.set_window(np.ones(N - 1, np.float32)) is False
+    assert blk.set_window(np.ones(N, np.float32)) is True
+
+
+def test_fft_linearity_and_parseval_full_size(gpu):
+    """size-independent properties at the BASELINE size (4096-pt, 4096 vectors = 2^24 samples)"""
+    rng = np.random.default_rng(9)
+    N, nvec = 4096, 4096
+    a = _rc(rng, N * nvec)
+    f = gpu.fft_vcc(N, True, [], False)
+    A = f.work(nvec, a)
+    # Parseval per vector
+    ea = (np.abs(a.reshape(nvec, N)) ** 2).sum(1)
+    eA = (np.abs(A.reshape(nvec, N)) ** 2).sum(1) / N
+    assert np.abs(eA / ea - 1).max() < 1e-5
+    # inverse(forward(x)) == N x
+    back = gpu.fft_vcc(N, False, [], False).work(nvec, A)
+    assert rel_err_max(back / N, a) < 5e-6
+
+
+def test_fft_errors(gpu):
+    with pytest.raises(gpu.GrhipError) as e:
+        gpu.fft_vcc(0, True, [], False)
+    assert e.value.code == -2
+    with pytest.raises(gpu.GrhipError):
+        gpu.fft_vcc(48, True, [], False)
+
+
+def _pfb_streams(x, M, tpf):
+    return [np.concatenate([np.zeros(tpf, np.complex64), x[j::M]]) for j in range(M)]
+
+
+@pytest.mark.parametrize("M,ntaps", [(8, 256), (8, 250), (4, 33), (16, 64), (3, 10), (1, 5)])
+def test_pfb_vs_oracle(gpu, po, M, ntaps):
+    rng = np.random.default_rng(M * 1000 + ntaps)
+    nout = 1500
+    taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+    x = _rc(rng, M * nout)
+    o = po.PfbChannelizer(M, taps, 1.0)
+    streams = _pfb_streams(x, M, o.taps_per_filter)
+    ref, used_ref = o.general_work(nout, streams)
+    blk = gpu.pfb_channelizer_ccf(M, taps, 1.0)
+    assert blk.history() == o.taps_per_filter + 1
+    assert blk.output_multiple() == o.output_multiple
+    out0, used0 = blk.general_work(nout, streams)
+    assert len(out0) == 0 and used0 == 0          # d_updated from the ctor's set_taps (.cc:169-172)
+    out, used = blk.general_work(nout, streams)
+    assert used == used_ref == nout
+    assert rel_err_max(out, ref) <= 1e-5
+
+
+@pytest.mark.parametrize("M,os_rate", [(8, 2.0), (8, 4.0), (6, 1.5), (4, 4.0)])
+def test_pfb_oversampled(gpu, po, M, os_rate):
+    rng = np.random.default_rng(int(M * 10 + os_rate))
+    taps = rng.uniform(-1, 1, 5 * M).astype(np.float32)
+    o = po.PfbChannelizer(M, taps, os_rate)
+    nout = 40 * o.output_multiple * int(os_rate * 2)
+    nin = int(round(nout / os_rate))
+    x = _rc(rng, M * (nin + 4))
+    streams = _pfb_streams(x, M, o.taps_per_filter)
+    ref, used_ref = o.general_work(nout, streams)
+    blk = gpu.pfb_channelizer_ccf(M, taps, os_rate)
+    blk.general_work(nout, streams)
+    out, used = blk.general_work(nout, streams)
+    assert used == used_ref
+    assert rel_err_max(out, ref) <= 1e-5
+
+
+def test_pfb_errors(gpu):
+    with pytest.raises(gpu.GrhipError) as e:
+        gpu.pfb_channelizer_ccf(8, np.ones(16, np.float32), 3.0)
+    assert e.value.code == -1          # std::invalid_argument
+
+
+def test_pfb_tone_lands_in_its_channel_full_size(gpu, wl):
+    """BASELINE cfg3 size: M=8, 256-tap prototype, 2^21 samples per call x 8 ... a tone
+    in channel k comes out in output bin k (property test, size independent)."""
+    M, nout = 8, 1 << 18
+    taps = wl.lowpass_taps(256, 0.5 / M, 1.0) * 1.0
+    blk = gpu.pfb_channelizer_ccf(M, taps, 1.0)
+    n = M * nout
+    t = np.arange(n)
+    for k in (1, 3, 6):
+        x = np.exp(2j * np.pi * (k / M + 0.01) * t).astype(np.complex64)
+        streams = _pfb_streams(x, M, 32)
+        blk.general_work(nout, streams)
+        out, _ = blk.general_work(nout, streams)
+        p = (np.abs(out[1000:]) ** 2).mean(0)
+        assert np.argmax(p) == k and p[k] > 100 * np.delete(p, k).max()

@@ -21,7 +21,7 @@ def _rand_c(rng, n):
 def test_fir_generic_mode_bit_exact(gpu, po, kind, ntaps, decim):
     rng = np.random.default_rng(ntaps * 10 + decim)
     n = 3001
-    nin = (n - 1) * decim + ntaps
+    nin = n * decim + ntaps - 1          # what the scheduler guarantees (gr_sync_decimator.cc:46-50)
     if kind == "fff":
         x = rng.uniform(-1, 1, nin).astype(np.float32)
         taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
@@ -48,7 +48,7 @@ def test_fir_generic_mode_bit_exact(gpu, po, kind, ntaps, decim):
 def test_fir_fast_mode_tolerance(gpu, po, kind, ntaps, decim):
     rng = np.random.default_rng(1000 + ntaps * 10 + decim)
     n = 5003           # not a multiple of the tile: exercises the ragged tail
-    nin = (n - 1) * decim + ntaps
+    nin = n * decim + ntaps - 1          # what the scheduler guarantees (gr_sync_decimator.cc:46-50)
     x = _rand_c(rng, nin)
     if kind == "ccf":
         taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
