@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--captures", type=int, default=16, help="captures per GPU per step")
     ap.add_argument("--samples", type=int, default=10_000_000, help="complex samples per capture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-capture-launch", action="store_true",
+                    help="one work_device() call per capture (block API) instead of one batched launch")
     ap.add_argument("--cpu-samples", type=int, default=10_000_000)
     return ap.parse_args()
 
@@ -144,24 +146,37 @@ def main():
     B = a.captures
     hist = len(proto) - 1
     nout = n // c["decim"]
-    # captures in HBM, each with its ntaps-1 history zeros in front (what the
-    # scheduler presents to a fresh block, runtime/gr_flat_flowgraph.cc:150)
-    row = ((hist + n + 63) // 64) * 64
+    # B captures resident in HBM, back to back rows (no history in front: the
+    # kernel supplies the ntaps-1 zeros a fresh flowgraph preloads,
+    # runtime/gr_flat_flowgraph.cc:150)
+    row = ((n + 63) // 64) * 64
     buf = torch.zeros((B, row, 2), dtype=torch.float32, device=dev)
     caps = synth_captures(torch, wl, B, n, rank * B, dev)
-    buf[:, hist:hist + n, :] = caps
+    buf[:, :n, :] = caps
     x0_host = caps[0].cpu().numpy().reshape(-1).view(np.complex64).copy() if rank == 0 else None
     del caps
-    out = torch.empty((B, ((nout + 63) // 64) * 64), dtype=torch.float32, device=dev)
+    orow = ((nout + 63) // 64) * 64
+    out = torch.empty((B, orow), dtype=torch.float32, device=dev)
 
     blk = g.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], device=local_rank)
     # a real (non-null) stream: the kernels, and the events that time them, all go here
     stream = torch.cuda.Stream(device=dev)
+    launches_per_step = 1 if not a.per_capture_launch else B
 
     def step():
-        for b in range(B):
-            blk.reset()
-            blk.work_device(nout, buf[b], out[b], stream)
+        if a.per_capture_launch:
+            hist_buf = step.hist_buf
+            for b in range(B):
+                blk.reset()
+                blk.work_device(nout, hist_buf[b], out[b], stream)
+        else:
+            # one launch of the fused kernel over the whole batch of captures
+            blk.run_captures_device(B, n, buf, row, out, orow, stream)
+
+    if a.per_capture_launch:   # block-API form: history zeros materialised in front of each capture
+        hrow = ((hist + n + 63) // 64) * 64
+        step.hist_buf = torch.zeros((B, hrow, 2), dtype=torch.float32, device=dev)
+        step.hist_buf[:, hist:hist + n, :] = buf[:, :n, :]
 
     torch.cuda.synchronize()
     for _ in range(a.warmup):
@@ -191,11 +206,12 @@ def main():
     if rank == 0:
         total_samples = float(world) * B * n * a.steps
         value = total_samples / elapsed / 1e6
-        launches = B * a.steps
+        launches = launches_per_step * a.steps
         k_ms = dev_ms / launches                      # the only kernel in the timed region
-        alg_bytes = (8.0 + 4.0 / c["decim"]) * n      # 9 B per input sample, fused
+        # 9 B per input sample (8 in + 4/decim out), fused; x samples per launch
+        alg_bytes = (8.0 + 4.0 / c["decim"]) * n * (B / launches_per_step)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        flops = (2.0 * 2.0 * c["ntaps"] / c["decim"] + 8.0) * n   # pre-mix + real-tap MACs
+        flops = (2.0 * 2.0 * c["ntaps"] / c["decim"] + 8.0) * n * (B / launches_per_step)   # pre-mix + real-tap MACs
         res = {
             "metric": "Msamples/s through FIR->demod chain @256 taps",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -345,6 +345,16 @@ class xlating_demod(_Block):
         return _check(L.grhip_xlating_demod_work_device(self._h, int(noutput_items), _devptr(d_in),
                                                         _devptr(d_out), _stream(stream)))
 
+    def run_captures_device(self, n_streams, n_samples, d_in, in_stride_items, d_out, out_stride_items,
+                            stream=None):
+        """n_streams fresh-state captures (no history in front) in one launch"""
+        L = lib()
+        L.grhip_xlating_demod_run_captures_device.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p,
+                                                              C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        return _check(L.grhip_xlating_demod_run_captures_device(
+            self._h, int(n_streams), int(n_samples), _devptr(d_in), int(in_stride_items), _devptr(d_out),
+            int(out_stride_items), _stream(stream)))
+
 
 # ----------------------------------------------------------------------------
 # digital.clock_recovery_mm_ff

@@ -20,7 +20,7 @@ static int pack_phase_major(const float *c, int T, int tw, int D, std::vector<fl
     int per = (T + D - 1) / D;
     int Tq = ((per + R - 1) / R) * R;
     if (Tq == 0) Tq = R;
-    hp.assign((size_t)D * Tq * tw, 0.f);
+    hp.assign(((size_t)D * Tq + R) * tw, 0.f);     // + R taps: the kernel prefetches one iteration ahead
     for (int k = 0; k < T; ++k) {
         int p = k % D, q = k / D;
         for (int w = 0; w < tw; ++w) hp[((size_t)p * Tq + q) * tw + w] = c[(size_t)k * tw + w];
@@ -83,18 +83,24 @@ int XlatingCore::build(int device)
         rc = upload(d_hp, hp.data(), hp.size() * sizeof(float));
         if (rc) return rc;
         if (premix) {
-            // W[u] = exp(j w (u - D)),  V[j'] = exp(-j w (j'-1) D), computed in double
+            // phasor tables of the pre-mix form, computed in double (see fir_tiled.hip)
             const int NT = tiled_NT();
-            const int Lu = (NT + Tq) * decim;
-            std::vector<cf> W(Lu), V(NT + 1);
-            for (int u = 0; u < Lu; ++u) {
-                double ang = omega * (double)(u - decim);
-                W[u] = cf((float)cos(ang), (float)sin(ang));
+            std::vector<cf> W(tiled_wtab_len()), V(NT + 1), S(tiled_stab_len());
+            for (int v = -1; v < (int)W.size() - 1; ++v) {
+                double ang = omega * (double)(v - decim);
+                W[v + 1] = cf((float)cos(ang), (float)sin(ang));
             }
-            for (int j = 0; j <= NT; ++j) {
-                double ang = -omega * (double)(j - 1) * (double)decim;
+            for (int i = 0; i < (int)S.size(); ++i) {
+                double ang = omega * 512.0 * (double)i;
+                S[i] = cf((float)cos(ang), (float)sin(ang));
+            }
+            for (int j = 0; j < NT; ++j) {
+                double ang = -omega * (double)j * (double)decim;
                 V[j] = cf((float)cos(ang), (float)sin(ang));
             }
+            V[NT] = cf((float)cos(omega * decim), (float)sin(omega * decim));
+            rc = upload(d_stab, S.data(), S.size() * sizeof(cf));
+            if (rc) return rc;
             rc = upload(d_wtab, W.data(), W.size() * sizeof(cf));
             if (rc) return rc;
             rc = upload(d_vtab, V.data(), V.size() * sizeof(cf));
@@ -163,7 +169,7 @@ int XlatingCore::ensure_rot(long long n, const float2 **gtab)
 
 void XlatingCore::release()
 {
-    d_taps_generic.release(); d_hp.release(); d_wtab.release(); d_vtab.release(); d_rot.release();
+    d_taps_generic.release(); d_hp.release(); d_wtab.release(); d_stab.release(); d_vtab.release(); d_rot.release();
     scratch_y.release();
 }
 
@@ -184,7 +190,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         memset(&a, 0, sizeof(a));
         a.x = d_in; a.x_stride = x_stride; a.n_in = n_in; a.n_lo = n_lo;
         a.hp = d_hp.as<float>(); a.Tq = Tq; a.n_out = n_out;
-        a.wtab = d_wtab.as<float2>(); a.vtab = d_vtab.as<float2>(); a.gtab = gtab;
+        a.wtab = d_wtab.as<float2>(); a.stab = d_stab.as<float2>(); a.vtab = d_vtab.as<float2>(); a.gtab = gtab;
         a.y_out = d_y; a.d_out = d_demod; a.gain = gain;
         a.y_stride = out_stride; a.d_stride = out_stride;
         a.y_prev = y_prev; a.y_last = y_last; a.atan_tab = atan_tab;
@@ -695,6 +701,30 @@ int grhip_xlating_demod_work_device(grhip_xlating_demod *h, int noutput_items, c
     h->cur ^= 1;
     h->fresh = false;
     return noutput_items;
+}
+
+int grhip_xlating_demod_run_captures_device(grhip_xlating_demod *h, int n_streams, size_t n_samples,
+                                            const void *d_in, size_t in_stride_items, void *d_out,
+                                            size_t out_stride_items, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (n_streams < 1) return fail(GRHIP_EINVAL, "n_streams must be >= 1");
+    int rc = h->bind();
+    if (rc) return rc;
+    const long long n_out = (long long)(n_samples / (size_t)h->core.decim);
+    if (n_out <= 0) return GRHIP_OK;
+    if (!(h->mode == GRHIP_MODE_FAST && h->core.use_tiled))
+        return fail(GRHIP_EINVAL, "run_captures needs the tiled path (FAST mode, supported decimation)");
+    if (h->core.tab_start != 0)
+        return fail(GRHIP_EINVAL, "handle has streamed past its cached rotator table; use a fresh handle");
+    const long long hist = h->core.ntaps > 0 ? h->core.ntaps - 1 : 0;
+    const long long keep = h->core.pos;
+    h->core.pos = 0;                                  // every capture starts at rotator phase 1
+    rc = h->core.run(GRHIP_MODE_FAST, (const float2 *)d_in - hist, hist + (long long)n_samples, n_out, nullptr,
+                     (float *)d_out, h->gain, nullptr, nullptr, h->tabs->atan_tab, h->pick(stream), n_streams,
+                     (long long)in_stride_items, hist, (long long)out_stride_items);
+    h->core.pos = keep;
+    return rc;
 }
 
 int grhip_xlating_demod_work(grhip_xlating_demod *h, int noutput_items, const void *in, void *out)

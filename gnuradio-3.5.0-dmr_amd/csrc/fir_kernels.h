@@ -23,8 +23,10 @@ struct FirTiledArgs {
     const float *hp;        // phase-major padded taps [D][Tq] (x2 floats if complex)
     int Tq;                 // taps per phase, multiple of R
     long long n_out;        // outputs per stream
-    const float2 *wtab;     // PREMIX: W[u], u in [0,(NT+Tq)*D)
-    const float2 *vtab;     // PREMIX: V[j'], j' in [0,NT]
+    const float2 *wtab;     // PREMIX: wtab[v+1] = e^{jw(v-D)}, v = -1..511 (tiled_wtab_len entries)
+    const float2 *stab;     // PREMIX: stab[i] = e^{jw 512 i}, i < tiled_stab_len()
+    const float2 *vtab;     // PREMIX: vtab[j] = e^{-jw j D}, j < NT; vtab[NT] = e^{+jwD} (boundary output)
+    int n_streams;          // filled in by launch_fir_tiled
     const float2 *gtab;     // EPI>=1: rotator phase per output of this call (stream-independent)
     float2 *y_out;          // EPI 0/1
     long long y_stride;
@@ -43,7 +45,9 @@ enum { EPI_NONE = 0, EPI_ROTATE = 1, EPI_ROTATE_DEMOD = 2 };
 // returns GRHIP_OK or <0 ; `decim` must be one of tiled_supported_decim().
 bool tiled_supported(int decim, int ntaps_padded_per_phase);
 int tiled_R();                      // outputs per lane
-int tiled_NT();                     // outputs per workgroup
+int tiled_NT();                     // outputs per workgroup tile
+int tiled_wtab_len();
+int tiled_stab_len();
 int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiledArgs &a,
                      int n_streams, hipStream_t st);
 

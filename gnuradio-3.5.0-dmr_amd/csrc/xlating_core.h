@@ -28,7 +28,7 @@ struct XlatingCore {
     std::complex<float> incr{1.f, 0.f};         // normalised d_phase_incr
     double omega = 0;                           // (double)(float)fwT0
     DevBuf d_taps_generic;                      // ctaps (d_taps order of the inner gr_fir_ccc)
-    DevBuf d_hp, d_wtab, d_vtab;                // tiled kernel operands
+    DevBuf d_hp, d_wtab, d_stab, d_vtab;        // tiled kernel operands
     int Tq = 0;
     bool use_tiled = false, premix = false;
     DevBuf scratch_y;

@@ -166,6 +166,17 @@ GRHIP_API int grhip_xlating_demod_work(grhip_xlating_demod *h, int noutput_items
                                        void *out);
 GRHIP_API int grhip_xlating_demod_work_device(grhip_xlating_demod *h, int noutput_items,
                                               const void *d_in, void *d_out, void *stream);
+/* n_streams independent captures in ONE launch, every one of them processed
+ * like a fresh block instance (rotator phase 1, demodulator history 0): what
+ * n_streams flowgraphs with identical parameters compute.  Capture s starts at
+ * d_in + s*in_stride_items complex items and has NO history in front (the
+ * ntaps-1 zeros a fresh flowgraph preloads are supplied by the kernel);
+ * n_samples items each; output s at d_out + s*out_stride_items floats,
+ * n_samples/decimation items.  Does not touch the handle's streaming state. */
+GRHIP_API int grhip_xlating_demod_run_captures_device(grhip_xlating_demod *h, int n_streams,
+                                                      size_t n_samples, const void *d_in,
+                                                      size_t in_stride_items, void *d_out,
+                                                      size_t out_stride_items, void *stream);
 
 /* ======================================================================
  * digital_clock_recovery_mm_ff
