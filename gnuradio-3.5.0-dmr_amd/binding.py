@@ -27,7 +27,8 @@ class GrhipError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libgrhip.so")
+    # GRHIP_LIB: load another build of the same library (diagnostic builds only)
+    return os.environ.get("GRHIP_LIB") or os.path.join(_HERE, "libgrhip.so")
 
 
 def lib():

@@ -37,11 +37,17 @@ __device__ __forceinline__ float fast_atan2f(float y, float x, const float *__re
     if (y_abs < x_abs) z = y_abs / x_abs;                  // :140 (IEEE divide)
     else               z = x_abs / y_abs;
 
-    if ((double)z < 0.003921569) {                         // :147 TAN_MAP_RES, double compare
+    // :147 `z < TAN_MAP_RES` compares in double against 0.003921569.  For a binary32 z
+    // that is exactly `z < 0x1.010104p-8f` (0x3b808082, the smallest float >= the
+    // constant), so no double arithmetic is needed.
+    // :151 `z * (REAL)256 - .5`: the product is exact (power of two) and the double
+    // subtraction is exact before narrowing, i.e. one float subtraction.
+    if (z < __builtin_bit_cast(float, 0x3b808082u)) {
         base_angle = z;
     } else {
-        alpha = (float)((double)(z * 256.0f) - 0.5);       // :151
+        alpha = z * 256.0f - 0.5f;
         index = (int)alpha;
+        index = index < 0 ? 0 : (index > 255 ? 255 : index);   // no-op for finite input; keeps NaN in bounds
         alpha -= (float)index;
         float t0 = tab[index], t1 = tab[index + 1];
         base_angle = t0;

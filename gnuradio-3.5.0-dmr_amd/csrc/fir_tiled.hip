@@ -38,12 +38,19 @@
 
 namespace grhip {
 
-constexpr int TILED_R = 8;
-constexpr int TILED_LOGR = 3;
+// R = outputs per lane.  R = 8: one LDS read per 8 packed FMAs, 2 workgroups (8 waves)
+// per CU.  R = 4: twice the LDS reads per FMA but 3 workgroups (12 waves) per CU.
+#ifndef GRHIP_TILED_R
+#define GRHIP_TILED_R 8
+#endif
+constexpr int TILED_R = GRHIP_TILED_R;
+constexpr int TILED_LOGR = TILED_R == 8 ? 3 : 2;
+static_assert(TILED_R == 8 || TILED_R == 4, "R must be 4 or 8");
 constexpr int TILED_THREADS = 256;
 constexpr int TILED_NT = TILED_THREADS * TILED_R;
-constexpr int TILED_NI = 18;                 // 16-byte loads per lane per tile (upper bound)
-constexpr int TILED_LDS_LIMIT = 80 * 1024;   // two workgroups per CU
+constexpr int TILED_WG_PER_CU = TILED_R == 8 ? 2 : 3;
+constexpr int TILED_NI = TILED_R == 8 ? 18 : 11;       // 16-byte loads per lane per tile (upper bound)
+constexpr int TILED_LDS_LIMIT = (160 * 1024) / TILED_WG_PER_CU - 256;
 
 int tiled_R() { return TILED_R; }
 int tiled_NT() { return TILED_NT; }
@@ -65,7 +72,8 @@ __host__ __device__ inline int tiled_phase_stride(int Tq)
 }
 __host__ inline size_t tiled_lds_bytes(int D, int Tq)
 {
-    return (size_t)D * tiled_phase_stride(Tq) * sizeof(float2) + (TILED_THREADS + 8) * sizeof(float2);
+    return (size_t)D * tiled_phase_stride(Tq) * sizeof(float2) + (TILED_THREADS + 8) * sizeof(float2) +
+           260 * sizeof(float);      // exchange area + arctangent table
 }
 
 bool tiled_supported(int decim, int Tq)
@@ -76,8 +84,27 @@ bool tiled_supported(int decim, int Tq)
     return tiled_lds_bytes(decim, Tq) <= (size_t)TILED_LDS_LIMIT;
 }
 
+// Diagnostic build only (-DGRHIP_STAMP, `make stamp`): per-wave cycle shares of the
+// phases of a tile, written to a buffer of their own (never to an output).
+#ifdef GRHIP_STAMP
+__device__ unsigned long long *g_stamp_buf = nullptr;
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now()
+#define STAMP(k) do { unsigned long long n__ = stamp_now(); st_acc[k] += n__ - st_last; st_last = n__; } while (0)
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#endif
+
 template <int D, bool CTAPS, bool PREMIX, int EPI>
-__global__ void __launch_bounds__(TILED_THREADS, 2) fir_tiled_kernel(const FirTiledArgs a)
+__global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kernel(const FirTiledArgs a)
 {
     constexpr int R = TILED_R, LOGR = TILED_LOGR, NT = TILED_NT, NI = TILED_NI;
     constexpr int LOGD = ilog2(D);
@@ -90,8 +117,9 @@ __global__ void __launch_bounds__(TILED_THREADS, 2) fir_tiled_kernel(const FirTi
     const int PS = tiled_phase_stride(Tq);
     float2 *red = xs + (size_t)D * PS;              // [TILED_THREADS + 8] exchange area
     const int Lu = (NT + Tq) * D;                   // samples per tile, u = 0 <-> (n0-1)*D
-    const long long tiles_per_stream = (a.n_out + NT - 1) / NT;
-    const long long total_tiles = tiles_per_stream * a.n_streams;
+    // tiles are numbered (stream, tile-in-stream); the pair is advanced incrementally
+    // (a 64-bit division per tile costs ~150 scalar instructions)
+    const int tiles_per_stream = (int)((a.n_out + NT - 1) / NT);
     const cfloat_p hp = (cfloat_p)a.hp;             // phase-major taps, padded by R entries
     const cfloat_p stab = (cfloat_p)a.stab;
 
@@ -104,119 +132,224 @@ __global__ void __launch_bounds__(TILED_THREADS, 2) fir_tiled_kernel(const FirTi
         wC = a.wtab[2 * t + 2];
     }
 
+    // per-lane output phase corrections of the pre-mix form (tile independent)
+    float2 vreg[R];
+    if (PREMIX) {
+        const float4 *vv = reinterpret_cast<const float4 *>(a.vtab + t * R);   // 64-byte aligned
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            const float4 v2 = vv[r >> 1];
+            vreg[r] = make_float2(v2.x, v2.y);
+            vreg[r + 1] = make_float2(v2.z, v2.w);
+        }
+    }
+    // arctangent table of the fused demodulator lives in LDS (1 KB)
+    float *s_atan = reinterpret_cast<float *>(red + TILED_THREADS + 8);
+    if (EPI == EPI_ROTATE_DEMOD) {
+        for (int i = t; i < 257; i += TILED_THREADS) s_atan[i] = a.atan_tab[i];
+    }
+
+    // lane constants of the per-wave predecessor computation: taps k = lane + 64 c,
+    // and the wave's phase correction of the pre-mix form
+    constexpr int PB = 8;
+    const bool pb_in_regs = Tq * D <= 64 * PB;
+    float hb[PB * TW];
+    float2 vb = make_float2(1.f, 0.f);
+    if (EPI == EPI_ROTATE_DEMOD) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {
+            const int k = (t & 63) + 64 * c;
+            const int kk = (k < Tq * D && pb_in_regs) ? k : 0;
+            const int idx = (kk & (D - 1)) * Tq + (kk >> LOGD);
+#pragma unroll
+            for (int w2 = 0; w2 < TW; ++w2) hb[c * TW + w2] = a.hp[idx * TW + w2];
+        }
+        const int jb = (NT / 4) * (t >> 6);             // tile-local index + 1 of the predecessor
+        if (PREMIX) vb = a.vtab[jb == 0 ? NT : jb - 1];
+    }
+
     float4 pf[NI];
+    float2 gb = make_float2(1.f, 0.f);     // rotator phase of the wave's predecessor output
+    float2 gq[R];                          // rotator phases of the lane's outputs
 
     // tile -> stream pointer, first global sample, load parity; returns true when
     // every 16-byte pair of the tile lies inside [n_lo, n_in) (all but the first
     // and last tiles of a stream)
-    auto tile_geom = [&](long long tile, const float2 *&x, long long &g0, int &off) {
-        const long long s = tile / tiles_per_stream;
-        const long long n0 = (tile - s * tiles_per_stream) * NT;
+    auto tile_geom = [&](int s, int b, const float2 *&x, long long &g0, int &off) {
+        const long long n0 = (long long)b * NT;
         x = a.x + s * a.x_stride;
         g0 = (n0 - 1) * D;
         const long long unit0 = (long long)(((unsigned long long)(uintptr_t)x) >> 3) + g0;
         off = (int)(unit0 & 1);                     // pair starts on a 16-byte boundary
-        return (g0 - 1 >= a.n_lo) && (g0 + Lu + 1 < a.n_in);
+        return (g0 - 1 >= a.n_lo) && (g0 + 2 * TILED_THREADS * NI + 1 < a.n_in);
+    };
+
+    // ---- rotator phases of a tile's outputs (issued at the end of the previous tile:
+    //      a full stage + MAC phase ahead of their use, single register set) ----------
+    auto fetch_phases = [&](int b) {
+        if (EPI >= EPI_ROTATE) {
+            // uniform base + 32-bit lane offsets; indices clamped to the last valid output
+            const float2 *gt = a.gtab + (long long)b * NT;
+            const long long left = a.n_out - (long long)b * NT;
+            const int lim = (int)(left < NT ? left : NT) - 1;          // last valid tile-local index
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int j = t * R + r;
+                gq[r] = gt[j < lim ? j : lim];
+            }
+            if (EPI == EPI_ROTATE_DEMOD) {
+                const int jb = (NT / 4) * (t >> 6) - 1;
+                gb = (b == 0 && jb < 0) ? make_float2(1.f, 0.f) : gt[jb];
+            }
+        }
     };
 
     // ---- issue the HBM loads of one tile into registers (branch-free) ----------
-    auto fetch = [&](long long tile) {
+    auto fetch = [&](int s, int b) {
         const float2 *x; long long g0; int off;
-        const bool inside = tile_geom(tile, x, g0, off);
-        const float4 *base = reinterpret_cast<const float4 *>(x + (g0 - off + 2 * t));
+        const bool inside = tile_geom(s, b, x, g0, off);
+        // uniform tile base; lane offset 16 t bytes; one 4 KB step per i
+        const char *xb = reinterpret_cast<const char *>(x + (g0 - off));
         if (inside && !(a.ablate & 1)) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int u = -off + 2 * t + 2 * TILED_THREADS * i;
-                // beyond the tile (only the last i): re-read the lane's first pair
-                pf[i] = base[(u < Lu) ? TILED_THREADS * i : 0];
-            }
+            for (int i = 0; i < NI; ++i)
+                pf[i] = reinterpret_cast<const float4 *>(xb + (size_t)i * (16 * TILED_THREADS))[t];
         } else {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int u = -off + 2 * t + 2 * TILED_THREADS * i;
-                const long long g = g0 + u;
-                const bool full = (u < Lu) && (g >= a.n_lo) && (g + 1 < a.n_in) && !(a.ablate & 1);
-                const float4 *src = full ? base + TILED_THREADS * i : reinterpret_cast<const float4 *>(a.hp);
-                pf[i] = *src;
-            }
+            for (int i = 0; i < NI; ++i) pf[i] = reinterpret_cast<const float4 *>(a.hp)[0];   // patched in stage()
         }
     };
 
     // ---- registers -> LDS, de-interleaved, pre-mixed ----------------------------
-    auto stage = [&](long long tile) {
+    // u = ub + 512 i  =>  m and the padded slot advance by constants per i:
+    // slot_i = slot_0 + (512/D)(1 + 1/R) i, so the LDS addresses are immediates.
+    auto stage = [&](int s, int b) {
         const float2 *x; long long g0; int off;
-        const bool inside = tile_geom(tile, x, g0, off) && !(a.ablate & 1);
+        const bool inside = tile_geom(s, b, x, g0, off) && !(a.ablate & 1);
         const float2 w0l = off ? wA : wB, w1l = off ? wB : wC;
         const int ub = -off + 2 * t;
+        constexpr int SLOT_STEP = (2 * TILED_THREADS / D) + (2 * TILED_THREADS / D) / R;
+        const int mm0 = (ub >> LOGD) - 1 + R, p0 = ub & (D - 1);
+        const int mm1 = ((ub + 1) >> LOGD) - 1 + R, p1 = (ub + 1) & (D - 1);
+        float2 *dst0 = xs + p0 * PS + mm0 + (mm0 >> LOGR);
+        float2 *dst1 = xs + p1 * PS + mm1 + (mm1 >> LOGR);
+        if (!inside) {
+            // first / last tile of a stream (or profiling ablation): bounds-checked
+            // loads straight from memory, same arithmetic, not unrolled (keeps the
+            // hot path's code small)
+#pragma nounroll
+            for (int i = 0; i < NI; ++i) {
+                const int u = ub + 2 * TILED_THREADS * i;
+                if (u >= Lu) break;
+                const long long g = g0 + u;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(a.ablate & 1)) {
+                    if (g >= a.n_lo && g < a.n_in) { float2 e = x[g]; v.x = e.x; v.y = e.y; }
+                    if (g + 1 >= a.n_lo && g + 1 < a.n_in) { float2 e = x[g + 1]; v.z = e.x; v.w = e.y; }
+                }
+                float2 e0 = make_float2(v.x, v.y), e1 = make_float2(v.z, v.w);
+                if (PREMIX) {
+                    const float2 si = make_float2(stab[2 * i], stab[2 * i + 1]);
+                    e0 = cmul_fma(e0, cmul_fma(w0l, si));
+                    e1 = cmul_fma(e1, cmul_fma(w1l, si));
+                }
+                if (u >= 0) dst0[SLOT_STEP * i] = e0;
+                if (u + 1 < Lu) dst1[SLOT_STEP * i] = e1;
+            }
+            return;
+        }
+        float sv[2 * NI];
+        if (PREMIX) {
+#pragma unroll
+            for (int k = 0; k < 2 * NI; ++k) sv[k] = stab[k];       // wave-uniform e^{jw 512 i}
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int u = ub + 2 * TILED_THREADS * i;
             if (u < Lu) {
-                float4 v = pf[i];
-                if (!inside) {          // rare: patch pairs that straddle the stream's ends
-                    const long long g = g0 + u;
-                    if (!((g >= a.n_lo) && (g + 1 < a.n_in)) || (a.ablate & 1)) {
-                        v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (!(a.ablate & 1)) {
-                            if (g >= a.n_lo && g < a.n_in) { float2 e = x[g]; v.x = e.x; v.y = e.y; }
-                            if (g + 1 >= a.n_lo && g + 1 < a.n_in) { float2 e = x[g + 1]; v.z = e.x; v.w = e.y; }
-                        }
-                    }
-                }
-                float2 e0 = make_float2(v.x, v.y), e1 = make_float2(v.z, v.w);
+                float2 e0 = make_float2(pf[i].x, pf[i].y), e1 = make_float2(pf[i].z, pf[i].w);
                 if (PREMIX) {
-                    const float2 si = make_float2(stab[2 * i], stab[2 * i + 1]);   // uniform e^{jw 512 i}
+                    const float2 si = make_float2(sv[2 * i], sv[2 * i + 1]);
                     e0 = cmul_fma(e0, cmul_fma(w0l, si));
                     e1 = cmul_fma(e1, cmul_fma(w1l, si));
                 }
-                if (u >= 0) {
-                    const int mm = (u >> LOGD) - 1 + R, p = u & (D - 1);
-                    xs[p * PS + mm + (mm >> LOGR)] = e0;
-                }
-                if (u + 1 < Lu) {
-                    const int u1 = u + 1;
-                    const int mm = (u1 >> LOGD) - 1 + R, p = u1 & (D - 1);
-                    xs[p * PS + mm + (mm >> LOGR)] = e1;
-                }
+                if (u >= 0) dst0[SLOT_STEP * i] = e0;
+                if (u + 1 < Lu) dst1[SLOT_STEP * i] = e1;
             }
         }
     };
 
-    long long tile = blockIdx.x;
-    if (tile < total_tiles) fetch(tile);
+    auto advance = [&](int &s, int &b) {
+        b += (int)gridDim.x;
+        while (b >= tiles_per_stream) { b -= tiles_per_stream; ++s; }
+    };
+    int s = 0, bidx = (int)blockIdx.x;
+    while (bidx >= tiles_per_stream) { bidx -= tiles_per_stream; ++s; }
+    if (s < a.n_streams) { fetch_phases(bidx); fetch(s, bidx); }
+    STAMP_DECL;
 
-    for (; tile < total_tiles; tile += gridDim.x) {
-        const long long s = tile / tiles_per_stream;
-        const long long bidx = tile - s * tiles_per_stream;
-        const long long n0 = bidx * NT;
+    while (s < a.n_streams) {
+        const long long n0 = (long long)bidx * NT;
+        int s_nxt = s, b_nxt = bidx;
+        advance(s_nxt, b_nxt);
 
-        stage(tile);
+        STAMP(7);
+        stage(s, bidx);
+        STAMP(0);
         __syncthreads();
+        STAMP(1);
         // next tile's HBM traffic flies under this tile's MAC loop
-        if (tile + gridDim.x < total_tiles) fetch(tile + gridDim.x);
+        if (s_nxt < a.n_streams) fetch(s_nxt, b_nxt);
+        STAMP(2);
 
-        // ---------------- boundary output y[n0-1] (fused demod only) -----------
+        // ---------------- predecessor of each WAVE's first output (fused demod) -----
+        // y[n0 + 512 w - 1] is recomputed by the 64 lanes of wave w (tree-order sum over
+        // the taps): no exchange between waves or workgroups, no barrier.  Its taps and
+        // phase factors are lane constants / were fetched a tile ahead, so nothing here
+        // queues behind the prefetch that was just issued.
         float2 yb = make_float2(0.f, 0.f);
         if (EPI == EPI_ROTATE_DEMOD) {
-            if (bidx == 0) {
+            const int wv = t >> 6, ln = t & 63;
+            if (bidx == 0 && wv == 0) {
                 yb = a.y_prev ? a.y_prev[s] : make_float2(0.f, 0.f);
             } else {
                 float2 part = make_float2(0.f, 0.f);
-                for (int k = t; k < Tq * D; k += TILED_THREADS) {
-                    const int p = k & (D - 1), q = k >> LOGD;
-                    const int mm = R - 1 + q;
-                    const float2 xv = xs[p * PS + mm + (mm >> LOGR)];
-                    if (CTAPS) {
-                        const float2 h = reinterpret_cast<const float2 *>(a.hp)[p * Tq + q];
-                        part.x = __builtin_fmaf(h.x, xv.x, part.x);
-                        part.x = __builtin_fmaf(-h.y, xv.y, part.x);
-                        part.y = __builtin_fmaf(h.x, xv.y, part.y);
-                        part.y = __builtin_fmaf(h.y, xv.x, part.y);
-                    } else {
-                        const float h = a.hp[p * Tq + q];
-                        part.x = __builtin_fmaf(h, xv.x, part.x);
-                        part.y = __builtin_fmaf(h, xv.y, part.y);
+                const int mb = (NT / 4) * wv + R - 1;          // mm of the output's first sample
+                if (pb_in_regs) {
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) {
+                        const int k = ln + 64 * c;
+                        if (k < Tq * D) {
+                            const int p = k & (D - 1), q = k >> LOGD;
+                            const int mm = mb + q;
+                            const float2 xv = xs[p * PS + mm + (mm >> LOGR)];
+                            if (CTAPS) {
+                                part.x = __builtin_fmaf(hb[2 * c], xv.x, part.x);
+                                part.x = __builtin_fmaf(-hb[2 * c + 1], xv.y, part.x);
+                                part.y = __builtin_fmaf(hb[2 * c], xv.y, part.y);
+                                part.y = __builtin_fmaf(hb[2 * c + 1], xv.x, part.y);
+                            } else {
+                                part.x = __builtin_fmaf(hb[c], xv.x, part.x);
+                                part.y = __builtin_fmaf(hb[c], xv.y, part.y);
+                            }
+                        }
+                    }
+                } else {
+                    for (int k = ln; k < Tq * D; k += 64) {
+                        const int p = k & (D - 1), q = k >> LOGD;
+                        const int mm = mb + q;
+                        const float2 xv = xs[p * PS + mm + (mm >> LOGR)];
+                        if (CTAPS) {
+                            const float hr = a.hp[2 * (p * Tq + q)], hi = a.hp[2 * (p * Tq + q) + 1];
+                            part.x = __builtin_fmaf(hr, xv.x, part.x);
+                            part.x = __builtin_fmaf(-hi, xv.y, part.x);
+                            part.y = __builtin_fmaf(hr, xv.y, part.y);
+                            part.y = __builtin_fmaf(hi, xv.x, part.y);
+                        } else {
+                            const float h = a.hp[p * Tq + q];
+                            part.x = __builtin_fmaf(h, xv.x, part.x);
+                            part.y = __builtin_fmaf(h, xv.y, part.y);
+                        }
                     }
                 }
 #pragma unroll
@@ -224,16 +357,13 @@ __global__ void __launch_bounds__(TILED_THREADS, 2) fir_tiled_kernel(const FirTi
                     part.x += __shfl_xor(part.x, o);
                     part.y += __shfl_xor(part.y, o);
                 }
-                if ((t & 63) == 0) red[TILED_THREADS + (t >> 6)] = part;
-                __syncthreads();
-                const float2 r0 = red[TILED_THREADS + 0], r1 = red[TILED_THREADS + 1];
-                const float2 r2 = red[TILED_THREADS + 2], r3 = red[TILED_THREADS + 3];
-                yb = make_float2((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y));
-                if (PREMIX) yb = cmul_fma(yb, a.vtab[NT]);
-                yb = cmul_ref(yb, a.gtab[n0 - 1]);
+                yb = part;
+                if (PREMIX) yb = cmul_fma(yb, vb);
+                yb = cmul_ref(yb, gb);
             }
         }
 
+        STAMP(3);
         // ---------------- MAC loop: R outputs per lane -----------------------------
         float2 acc[R];
 #pragma unroll
@@ -280,26 +410,16 @@ __global__ void __launch_bounds__(TILED_THREADS, 2) fir_tiled_kernel(const FirTi
             }
         }
 
+        STAMP(4);
         // ---------------- epilogue ---------------------------------------------------
         const long long nl = n0 + (long long)t * R;          // first output of this lane
         if (PREMIX) {
-            const float4 *vv = reinterpret_cast<const float4 *>(a.vtab + t * R);   // 64-byte aligned
 #pragma unroll
-            for (int r = 0; r < R; r += 2) {
-                const float4 v2 = vv[r >> 1];
-                acc[r] = cmul_fma(acc[r], make_float2(v2.x, v2.y));
-                acc[r + 1] = cmul_fma(acc[r + 1], make_float2(v2.z, v2.w));
-            }
+            for (int r = 0; r < R; ++r) acc[r] = cmul_fma(acc[r], vreg[r]);
         }
         if (EPI >= EPI_ROTATE) {
-            if (nl + R <= a.n_out) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r] = cmul_ref(acc[r], a.gtab[nl + r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (nl + r < a.n_out) acc[r] = cmul_ref(acc[r], a.gtab[nl + r]);
-            }
+            for (int r = 0; r < R; ++r) acc[r] = cmul_ref(acc[r], gq[r]);   // gr_rotator: z = in * d_phase
         }
 
         if (EPI != EPI_ROTATE_DEMOD) {
@@ -315,14 +435,16 @@ __global__ void __launch_bounds__(TILED_THREADS, 2) fir_tiled_kernel(const FirTi
                     if (nl + r < a.n_out) y[nl + r] = acc[r];
             }
         } else {
-            // previous output for r = 0 comes from the neighbouring lane
-            red[t] = acc[R - 1];
-            __syncthreads();
-            float2 prev = (t == 0) ? yb : red[t - 1];
+            // previous output for r = 0: the neighbouring lane's last one (DPP shift);
+            // lane 0 of every wave takes the wave's recomputed predecessor
+            float2 prev;
+            prev.x = __shfl_up(acc[R - 1].x, 1);
+            prev.y = __shfl_up(acc[R - 1].y, 1);
+            if ((t & 63) == 0) prev = yb;
             float d[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                d[r] = (a.ablate & 4) ? acc[r].x + prev.y : quad_demod_one(acc[r], prev, a.gain, a.atan_tab);
+                d[r] = (a.ablate & 4) ? acc[r].x + prev.y : quad_demod_one(acc[r], prev, a.gain, s_atan);
                 prev = acc[r];
             }
             float *__restrict__ o = a.d_out + s * a.d_stride;
@@ -343,8 +465,18 @@ __global__ void __launch_bounds__(TILED_THREADS, 2) fir_tiled_kernel(const FirTi
                     if (nl + r == last) a.y_last[s] = acc[r];
             }
         }
+        if (s_nxt < a.n_streams) fetch_phases(b_nxt);      // for the next tile's epilogue
+        STAMP(5);
         __syncthreads();        // xs / red are rewritten by the next tile
+        STAMP(6);
+        s = s_nxt; bidx = b_nxt;
     }
+#ifdef GRHIP_STAMP
+    if ((t & 63) == 0 && g_stamp_buf) {
+        unsigned long long *o = g_stamp_buf + ((size_t)blockIdx.x * (TILED_THREADS / 64) + (t >> 6)) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+    }
+#endif
 }
 
 static int g_num_cus = 0;
@@ -367,7 +499,7 @@ static int launch_tiled_inst(const FirTiledArgs &a, hipStream_t st)
         g_num_cus = n > 0 ? n : 256;
     }
     const long long tiles = ((a.n_out + TILED_NT - 1) / TILED_NT) * a.n_streams;
-    long long grid = 2ll * g_num_cus;                 // persistent: two workgroups per CU
+    long long grid = (long long)TILED_WG_PER_CU * g_num_cus;   // persistent workgroups
     if (grid > tiles) grid = tiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TILED_THREADS), lds, st, a);
     GRHIP_HIP(hipGetLastError());
@@ -394,6 +526,16 @@ static int launch_tiled_d(bool ctaps, bool premix, int epi, const FirTiledArgs &
     if (epi != EPI_NONE) return fail(GRHIP_EINVAL, "real taps without premix have no rotator");
     return launch_tiled_inst<D, false, false, EPI_NONE>(a, st);
 }
+
+#ifdef GRHIP_STAMP
+// debug hook (not part of the ABI): where the stamp sums go; needs 8 u64 per wave
+extern "C" __attribute__((visibility("default"))) int grdbg_set_stamp_buffer(void *d_buf)
+{
+    unsigned long long *p = (unsigned long long *)d_buf;
+    GRHIP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)));
+    return GRHIP_OK;
+}
+#endif
 
 int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiledArgs &a_in, int n_streams,
                      hipStream_t st)

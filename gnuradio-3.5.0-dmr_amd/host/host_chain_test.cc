@@ -1,0 +1,88 @@
+// host_chain_test.cc -- C++ drop-in test: builds the DMR chain out of the grhip
+// block wrappers exactly as a GNU Radio 3.5 C++ application would (factories
+// returning shared pointers, connect in order, run), through the stand-in
+// executor.  Reads the capture and parameters from files written by the pytest
+// that drives it and writes each stage's output for comparison with the oracle.
+//
+// usage: host_chain_test <dir> <mode: chain|errors>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "grhip_blocks.h"
+#include "grhip_executor.h"
+
+template <class T> static std::vector<T> slurp(const std::string &p)
+{
+    std::ifstream f(p, std::ios::binary);
+    if (!f) { std::cerr << "cannot open " << p << "\n"; exit(2); }
+    f.seekg(0, std::ios::end); size_t n = f.tellg(); f.seekg(0);
+    std::vector<T> v(n / sizeof(T));
+    f.read((char *)v.data(), n);
+    return v;
+}
+static void dump(const std::string &p, const std::vector<unsigned char> &v)
+{
+    std::ofstream f(p, std::ios::binary);
+    f.write((const char *)v.data(), v.size());
+}
+
+static int test_errors()
+{
+    int fails = 0;
+    try { grhip_make_clock_recovery_mm_ff(0.5f, 0.01f, 0.5f, 0.01f, 0.001f); fails++; }
+    catch (const std::out_of_range &) {}                       // digital_clock_recovery_mm_ff.cc:58-59
+    try { grhip_make_clock_recovery_mm_ff(2.f, -0.01f, 0.5f, 0.01f, 0.001f); fails++; }
+    catch (const std::out_of_range &) {}                       // .cc:60-61
+    try { grhip_make_correlate_access_code_bb(std::string(65, '1'), 0); fails++; }
+    catch (const std::out_of_range &) {}                       // digital_correlate_access_code_bb.cc:54-57
+    try { grhip_make_pfb_channelizer_ccf(8, std::vector<float>(16, 1.f), 3.0f); fails++; }
+    catch (const std::invalid_argument &) {}                   // gr_pfb_channelizer_ccf.cc:57-60
+    try { grhip_make_fft_vcc(0, true, std::vector<float>()); fails++; }
+    catch (const std::out_of_range &) {}                       // gri_fft.cc:104-105
+    grhip_correlate_access_code_bb_sptr c = grhip_make_correlate_access_code_bb("1011", 0);
+    if (c->set_access_code(std::string(65, '0'))) fails++;      // returns false, keeps old code
+    if (!c->set_access_code("110011")) fails++;
+    grhip_fir_filter_ccf_sptr f = grhip_make_fir_filter_ccf(4, std::vector<float>(64, 0.5f));
+    if (f->history() != 64 || f->decimation() != 4 || f->relative_rate() != 0.25) fails++;
+    grhip_quadrature_demod_cf_sptr q = grhip_make_quadrature_demod_cf(1.0f);
+    if (q->history() != 2) fails++;
+    std::cout << "errors test: " << (fails ? "FAIL" : "ok") << "\n";
+    return fails;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { std::cerr << "usage: host_chain_test <dir> <chain|errors>\n"; return 2; }
+    std::string dir = argv[1], mode = argv[2];
+    if (mode == "errors") return test_errors();
+
+    std::vector<gr_complex> x = slurp<gr_complex>(dir + "/x.c64");
+    std::vector<gr_complex> taps = slurp<gr_complex>(dir + "/taps.c64");
+    std::vector<double> p = slurp<double>(dir + "/params.f64");
+    // params: decim, center_freq, fs, demod_gain, omega, gain_omega, mu, gain_mu, rel_limit, threshold
+    std::vector<unsigned char> codev = slurp<unsigned char>(dir + "/code.txt");
+    std::string code(codev.begin(), codev.end());
+
+    gr_block_sptr xl = grhip_make_freq_xlating_fir_filter_ccc((int)p[0], taps, p[1], p[2]);
+    gr_block_sptr qd = grhip_make_quadrature_demod_cf((float)p[3]);
+    gr_block_sptr mm = grhip_make_clock_recovery_mm_ff((float)p[4], (float)p[5], (float)p[6], (float)p[7], (float)p[8]);
+    gr_block_sptr sl = grhip_make_binary_slicer_fb();
+    gr_block_sptr ca = grhip_make_correlate_access_code_bb(code, (int)p[9]);
+
+    {   // stage outputs, each through its own small graph so that they can be compared one by one
+        grhip_linear_flowgraph g1; g1.connect(xl); g1.connect(qd);
+        std::vector<unsigned char> dem = g1.run(x.data(), x.size());
+        dump(dir + "/demod.f32", dem);
+        grhip_linear_flowgraph g2; g2.connect(mm);
+        std::vector<unsigned char> soft = g2.run(dem.data(), dem.size() / 4);
+        dump(dir + "/soft.f32", soft);
+        grhip_linear_flowgraph g3; g3.connect(sl); g3.connect(ca);
+        std::vector<unsigned char> bits = g3.run(soft.data(), soft.size() / 4);
+        dump(dir + "/bits.u8", bits);
+    }
+    std::cout << "chain ok\n";
+    return 0;
+}
