@@ -114,6 +114,21 @@ def cpu_baseline(wl, x_host, proto, repeats=2):
     return res
 
 
+def measured_traffic(captures, samples, launches_per_step):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes (profiles/traffic.json: FETCH_SIZE doubled per the gfx950 correction for
+    16-byte coalesced streaming reads, + WRITE_SIZE), only when it was collected for
+    this exact configuration; otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        if t["captures"] == captures and t["samples"] == samples and launches_per_step == 1:
+            return t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     a = parse()
     import torch
@@ -134,13 +149,11 @@ def main():
     wl = g.workload
     c = wl.CFG2
 
-    # shared taps: built on rank 0, RCCL-broadcast over xGMI to the other ranks
-    proto_t = torch.zeros((c["ntaps"], 2), dtype=torch.float32, device=dev)
-    if rank == 0:
-        proto_t.copy_(torch.from_numpy(wl.cfg2_proto_taps().view(np.float32).reshape(-1, 2)))
-    if world > 1:
-        dist.broadcast(proto_t, src=0)
-    proto = proto_t.cpu().numpy().reshape(-1).view(np.complex64)
+    from grhip import dist as gd
+    # shared taps: built on rank 0 only, RCCL-broadcast over xGMI to the other ranks
+    # (the only collective on this path; captures are independent units)
+    proto = gd.broadcast_taps(wl.cfg2_proto_taps() if rank == 0 else np.zeros(1, np.complex64), dist, dev)
+    my_streams = gd.shard_streams(world * a.captures, rank, world)     # weak scaling: B captures per rank
 
     n = a.samples
     B = a.captures
@@ -151,7 +164,7 @@ def main():
     # runtime/gr_flat_flowgraph.cc:150)
     row = ((n + 63) // 64) * 64
     buf = torch.zeros((B, row, 2), dtype=torch.float32, device=dev)
-    caps = synth_captures(torch, wl, B, n, rank * B, dev)
+    caps = synth_captures(torch, wl, B, n, my_streams[0], dev)
     buf[:, :n, :] = caps
     x0_host = caps[0].cpu().numpy().reshape(-1).view(np.complex64).copy() if rank == 0 else None
     del caps
@@ -198,10 +211,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = gd.max_over_ranks(elapsed, dist, dev)
 
     if rank == 0:
         total_samples = float(world) * B * n * a.steps
@@ -223,7 +233,7 @@ def main():
                        "RCCL broadcast of taps only"},
             "roofline": {"bound": "hbm", "kernel": "fir_tiled_kernel<D=4,premix,rotate+demod>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, n, launches_per_step),
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "valu_tflops": flops / (k_ms * 1e-3) / 1e12,
                          "valu_frac_of_fp32_peak": flops / (k_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS},

@@ -103,6 +103,20 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #define STAMP(k)
 #endif
 
+// sum over the 64 lanes of a wave with DPP adds (no LDS traffic); every lane gets the
+// total.  quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror give each row of
+// 16 its sum; row_bcast15 / row_bcast31 carry it across rows into lane 63.
+__device__ __forceinline__ float wave_sum(float x)
+{
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 template <int D, bool CTAPS, bool PREMIX, int EPI>
 __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kernel(const FirTiledArgs a)
 {
@@ -279,16 +293,27 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         }
     };
 
+    // tile id = b * n_streams + s (streams fastest): the workgroups that run at the same
+    // time work on the same output range of different streams, so the shared rotator
+    // phase table is served from L2 instead of being re-read from HBM once per stream.
+    const int adv_b = (int)(gridDim.x / (unsigned)a.n_streams), adv_s = (int)(gridDim.x % (unsigned)a.n_streams);
     auto advance = [&](int &s, int &b) {
-        b += (int)gridDim.x;
-        while (b >= tiles_per_stream) { b -= tiles_per_stream; ++s; }
+        s += adv_s; b += adv_b;
+        if (s >= a.n_streams) { s -= a.n_streams; ++b; }
     };
-    int s = 0, bidx = (int)blockIdx.x;
-    while (bidx >= tiles_per_stream) { bidx -= tiles_per_stream; ++s; }
-    if (s < a.n_streams) { fetch_phases(bidx); fetch(s, bidx); }
+    int s = (int)(blockIdx.x % (unsigned)a.n_streams), bidx = (int)(blockIdx.x / (unsigned)a.n_streams);
+    // The workgroups that share a CU run identical phases; left alone they sit in the
+    // same phase at the same time (both in the MAC loop, or both waiting on memory).
+    // The later-dispatched half idles once for part of a tile so that one's MAC loop
+    // overlaps the other's staging / epilogue.  Speed only: any placement is correct.
+    if (a.stagger > 0 && blockIdx.x >= (gridDim.x + 1) / 2) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(8);
+    }
+    if (bidx < tiles_per_stream) { fetch_phases(bidx); fetch(s, bidx); }
     STAMP_DECL;
 
-    while (s < a.n_streams) {
+    while (bidx < tiles_per_stream) {
         const long long n0 = (long long)bidx * NT;
         int s_nxt = s, b_nxt = bidx;
         advance(s_nxt, b_nxt);
@@ -299,7 +324,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         __syncthreads();
         STAMP(1);
         // next tile's HBM traffic flies under this tile's MAC loop
-        if (s_nxt < a.n_streams) fetch(s_nxt, b_nxt);
+        if (b_nxt < tiles_per_stream) fetch(s_nxt, b_nxt);
         STAMP(2);
 
         // ---------------- predecessor of each WAVE's first output (fused demod) -----
@@ -352,12 +377,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
                         }
                     }
                 }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    part.x += __shfl_xor(part.x, o);
-                    part.y += __shfl_xor(part.y, o);
-                }
-                yb = part;
+                yb = make_float2(wave_sum(part.x), wave_sum(part.y));
                 if (PREMIX) yb = cmul_fma(yb, vb);
                 yb = cmul_ref(yb, gb);
             }
@@ -465,7 +485,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
                     if (nl + r == last) a.y_last[s] = acc[r];
             }
         }
-        if (s_nxt < a.n_streams) fetch_phases(b_nxt);      // for the next tile's epilogue
+        if (b_nxt < tiles_per_stream) fetch_phases(b_nxt);      // for the next tile's epilogue
         STAMP(5);
         __syncthreads();        // xs / red are rewritten by the next tile
         STAMP(6);
@@ -547,6 +567,9 @@ int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiled
     static int ablate = -1;
     if (ablate < 0) { const char *e = getenv("GRHIP_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
+    static int stagger = -1;
+    if (stagger < 0) { const char *e = getenv("GRHIP_STAGGER"); stagger = e ? atoi(e) : 8000; }   // measured: 3 % on cfg2
+    a.stagger = stagger;
     switch (decim) {
     case 1: return launch_tiled_d<1>(ctaps, premix, epi, a, st);
     case 2: return launch_tiled_d<2>(ctaps, premix, epi, a, st);
