@@ -186,16 +186,21 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     float2 gb = make_float2(1.f, 0.f);     // rotator phase of the wave's predecessor output
     float2 gq[R];                          // rotator phases of the lane's outputs
 
-    // tile -> stream pointer, first global sample, load parity; returns true when
-    // every 16-byte pair of the tile lies inside [n_lo, n_in) (all but the first
-    // and last tiles of a stream)
-    auto tile_geom = [&](int s, int b, const float2 *&x, long long &g0, int &off) {
-        const long long n0 = (long long)b * NT;
-        x = a.x + s * a.x_stride;
-        g0 = (n0 - 1) * D;
+    // tile -> buffer descriptor of its stream + byte offset of the lane's first pair.
+    // The stream is addressed through a raw buffer descriptor whose base is the first
+    // real item (index n_lo) and whose size is the readable part: lanes that fall
+    // before the stream (the history zeros of a fresh flowgraph) or past its end get
+    // zeros from the hardware range check (per dword), so there is no bounds code.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    auto tile_geom = [&](int s, int b, __amdgpu_buffer_rsrc_t &rsrc, int &voff, int &off) {
+        const float2 *x = a.x + (long long)s * a.x_stride + a.n_lo;       // first real item
+        const long long g0 = ((long long)b * NT - 1) * D - a.n_lo;        // tile start relative to it
         const long long unit0 = (long long)(((unsigned long long)(uintptr_t)x) >> 3) + g0;
         off = (int)(unit0 & 1);                     // pair starts on a 16-byte boundary
-        return (g0 - 1 >= a.n_lo) && (g0 + 2 * TILED_THREADS * NI + 1 < a.n_in);
+        const long long bytes = (a.ablate & 1) ? 0 : (a.n_in - a.n_lo) * 8;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x), 0, (int)bytes, 0x00020000);
+        voff = (int)((g0 - off) * 8) + 16 * t;      // may be negative: out of range => zeros
     };
 
     // ---- rotator phases of a tile's outputs (issued at the end of the previous tile:
@@ -218,19 +223,15 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         }
     };
 
-    // ---- issue the HBM loads of one tile into registers (branch-free) ----------
+    // ---- issue the HBM loads of one tile into registers ------------------------------
     auto fetch = [&](int s, int b) {
-        const float2 *x; long long g0; int off;
-        const bool inside = tile_geom(s, b, x, g0, off);
-        // uniform tile base; lane offset 16 t bytes; one 4 KB step per i
-        const char *xb = reinterpret_cast<const char *>(x + (g0 - off));
-        if (inside && !(a.ablate & 1)) {
+        __amdgpu_buffer_rsrc_t rsrc; int voff, off;
+        tile_geom(s, b, rsrc, voff, off);
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
-                pf[i] = reinterpret_cast<const float4 *>(xb + (size_t)i * (16 * TILED_THREADS))[t];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) pf[i] = reinterpret_cast<const float4 *>(a.hp)[0];   // patched in stage()
+        for (int i = 0; i < NI; ++i) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + i * (16 * TILED_THREADS), 0, 0);
+            const f32x4 f = __builtin_bit_cast(f32x4, v);
+            pf[i] = make_float4(f[0], f[1], f[2], f[3]);
         }
     };
 
@@ -238,8 +239,8 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     // u = ub + 512 i  =>  m and the padded slot advance by constants per i:
     // slot_i = slot_0 + (512/D)(1 + 1/R) i, so the LDS addresses are immediates.
     auto stage = [&](int s, int b) {
-        const float2 *x; long long g0; int off;
-        const bool inside = tile_geom(s, b, x, g0, off) && !(a.ablate & 1);
+        __amdgpu_buffer_rsrc_t rsrc; int voff, off;
+        tile_geom(s, b, rsrc, voff, off);
         const float2 w0l = off ? wA : wB, w1l = off ? wB : wC;
         const int ub = -off + 2 * t;
         constexpr int SLOT_STEP = (2 * TILED_THREADS / D) + (2 * TILED_THREADS / D) / R;
@@ -247,31 +248,6 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         const int mm1 = ((ub + 1) >> LOGD) - 1 + R, p1 = (ub + 1) & (D - 1);
         float2 *dst0 = xs + p0 * PS + mm0 + (mm0 >> LOGR);
         float2 *dst1 = xs + p1 * PS + mm1 + (mm1 >> LOGR);
-        if (!inside) {
-            // first / last tile of a stream (or profiling ablation): bounds-checked
-            // loads straight from memory, same arithmetic, not unrolled (keeps the
-            // hot path's code small)
-#pragma nounroll
-            for (int i = 0; i < NI; ++i) {
-                const int u = ub + 2 * TILED_THREADS * i;
-                if (u >= Lu) break;
-                const long long g = g0 + u;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(a.ablate & 1)) {
-                    if (g >= a.n_lo && g < a.n_in) { float2 e = x[g]; v.x = e.x; v.y = e.y; }
-                    if (g + 1 >= a.n_lo && g + 1 < a.n_in) { float2 e = x[g + 1]; v.z = e.x; v.w = e.y; }
-                }
-                float2 e0 = make_float2(v.x, v.y), e1 = make_float2(v.z, v.w);
-                if (PREMIX) {
-                    const float2 si = make_float2(stab[2 * i], stab[2 * i + 1]);
-                    e0 = cmul_fma(e0, cmul_fma(w0l, si));
-                    e1 = cmul_fma(e1, cmul_fma(w1l, si));
-                }
-                if (u >= 0) dst0[SLOT_STEP * i] = e0;
-                if (u + 1 < Lu) dst1[SLOT_STEP * i] = e1;
-            }
-            return;
-        }
         float sv[2 * NI];
         if (PREMIX) {
 #pragma unroll
@@ -323,7 +299,9 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         STAMP(0);
         __syncthreads();
         STAMP(1);
-        // next tile's HBM traffic flies under this tile's MAC loop
+        // next tile's HBM traffic flies under this tile's MAC loop.  (Issuing it in one
+        // burst per polyphase component instead was measured slower: unrolling the phase
+        // loop costs more registers than the 256-VGPR budget has.)
         if (b_nxt < tiles_per_stream) fetch(s_nxt, b_nxt);
         STAMP(2);
 
