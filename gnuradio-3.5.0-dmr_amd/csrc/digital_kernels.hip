@@ -147,7 +147,7 @@ int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipSt
 // then every lane emits 8 output bytes with one 8-byte store.  HBM-bound:
 // 1 B (or 4 B when the slicer is fused) in + 1 B out per item.
 // ===========================================================================
-constexpr int CORR_TB = 2048;
+constexpr int CORR_TB = 8192;     // outputs per workgroup (4 rounds of 8 per lane)
 constexpr int CORR_WORDS = CORR_TB / 64 + 2;
 
 __device__ __forceinline__ unsigned long long corr_word(const unsigned long long *P, long long w,
@@ -174,52 +174,110 @@ corr_kernel(CorrParams p, const CorrState *__restrict__ state_in, const unsigned
     const float *__restrict__ xf = in_soft ? in_soft + (long long)s * in_stride : nullptr;
     const CorrState st = state_in[s];
 
-    // words i0/64 - 2 .. i0/64 + CORR_TB/64 - 1
+    // words i0/64 - 2 .. i0/64 + CORR_TB/64 - 1, first item of a word at its MSB.
+    // Wide path: a lane takes 16 input bytes (or 8 floats) with 16-byte loads, squeezes
+    // their LSBs (sign decisions) into one 16-bit (8-bit) chunk with a multiply, and
+    // drops the chunk into its place inside the 64-bit word (little-endian LDS: chunk c
+    // of a word lives at sub-index last-c).  All loads of a lane are issued before the
+    // first is used.
     const long long wlo = i0 / 64 - 2;
-    for (int wi = t >> 6; wi < CORR_WORDS; wi += 4) {
-        long long w = wlo + wi;
-        long long idx = w * 64 + (t & 63);
-        int bit = 0;
-        if (idx >= 0 && idx < n) bit = xb ? (xb[idx] & 1) : (xf[idx] >= 0 ? 1 : 0);
-        unsigned long long m = __ballot(bit);            // lane l -> bit l
-        if ((t & 63) == 0) P[wi] = __brevll(m);          // first item at the MSB
+    const long long base = wlo * 64;                    // first item covered by P (may be < 0)
+    const bool wide = (base >= 0) && (base + (long long)CORR_WORDS * 64 <= n) &&
+                      ((((uintptr_t)(xb ? (const void *)(xb + base) : (const void *)(xf + base))) & 15) == 0);
+    if (wide && xb) {
+        constexpr int NCH = CORR_WORDS * 4;             // 16-item chunks
+        constexpr int PER = (NCH + 255) / 256;
+        uint4 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = t + 256 * k;
+            v[k] = (c < NCH) ? reinterpret_cast<const uint4 *>(xb + base)[c] : make_uint4(0, 0, 0, 0);
+        }
+        unsigned short *P16 = reinterpret_cast<unsigned short *>(P);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = t + 256 * k;
+            if (c < NCH) {
+                // ((w & 0x01010101) * 0x08040201) >> 24 : LSBs of bytes 0..3 -> bits 3..0
+                const unsigned n0 = (((v[k].x & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
+                const unsigned n1 = (((v[k].y & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
+                const unsigned n2 = (((v[k].z & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
+                const unsigned n3 = (((v[k].w & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
+                P16[(c & ~3) + (3 - (c & 3))] = (unsigned short)((n0 << 12) | (n1 << 8) | (n2 << 4) | n3);
+            }
+        }
+    } else if (wide && xf) {
+        constexpr int NCH = CORR_WORDS * 8;             // 8-item chunks
+        constexpr int PER = (NCH + 255) / 256;
+        float4 v[2 * PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = t + 256 * k;
+            const float4 *src = reinterpret_cast<const float4 *>(xf + base) + 2 * (c < NCH ? c : 0);
+            v[2 * k] = src[0];
+            v[2 * k + 1] = src[1];
+        }
+        unsigned char *P8 = reinterpret_cast<unsigned char *>(P);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = t + 256 * k;
+            if (c < NCH) {
+                const float4 a0 = v[2 * k], a1 = v[2 * k + 1];
+                const unsigned b = ((a0.x >= 0) << 7) | ((a0.y >= 0) << 6) | ((a0.z >= 0) << 5) | ((a0.w >= 0) << 4) |
+                                   ((a1.x >= 0) << 3) | ((a1.y >= 0) << 2) | ((a1.z >= 0) << 1) | (a1.w >= 0);
+                P8[(c & ~7) + (7 - (c & 7))] = (unsigned char)b;
+            }
+        }
+    } else {
+        // first / last tile of a stream, or unaligned input: one item per lane, wave ballot
+        for (int wi = t >> 6; wi < CORR_WORDS; wi += 4) {
+            long long w = wlo + wi;
+            long long idx = w * 64 + (t & 63);
+            int bit = 0;
+            if (idx >= 0 && idx < n) bit = xb ? (xb[idx] & 1) : (xf[idx] >= 0 ? 1 : 0);
+            unsigned long long m = __ballot(bit);            // lane l -> bit l
+            if ((t & 63) == 0) P[wi] = __brevll(m);          // first item at the MSB
+        }
     }
     __syncthreads();
 
-    unsigned long long packed = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const long long i = i0 + 8 * t + j;
-        unsigned o = 0;
-        if (i < n) {
-            // bit 0: stream bit i-64
-            long long b = i - 64;
-            long long w = b >> 6;                          // floor division (arithmetic shift)
-            int r = (int)(b & 63);
-            o |= (unsigned)((corr_word(P, w, wlo, st.data_reg) >> (63 - r)) & 1ull);
-            // bit 1: flags already in flight at call start
-            if (i < 64) o |= (unsigned)((st.flag_reg >> (63 - i)) & 1ull) << 1;
-            // bit 1: flag computed len items ago
-            long long k = i - (long long)p.len;
-            if (k >= 0 && p.len > 0) {
-                long long wk = k >> 6;
-                int rk = (int)(k & 63);
-                unsigned long long hi = corr_word(P, wk - 1, wlo, st.data_reg);
-                unsigned long long W = hi;
-                if (rk) W = (hi << rk) | (corr_word(P, wk, wlo, st.data_reg) >> (64 - rk));
-                unsigned nwrong = (unsigned)__popcll((W ^ p.access_code) & p.mask);
-                if (nwrong <= p.threshold) o |= 2u;
-            }
-        }
-        packed |= (unsigned long long)o << (8 * j);
-    }
     unsigned char *__restrict__ y = out + (long long)s * out_stride;
-    const long long o0 = i0 + 8 * t;
-    if (o0 + 8 <= n && ((((uintptr_t)(y + o0)) & 7) == 0)) {
-        *reinterpret_cast<unsigned long long *>(y + o0) = packed;
-    } else {
-        for (int j = 0; j < 8; ++j)
-            if (o0 + j < n) y[o0 + j] = (unsigned char)(packed >> (8 * j));
+    for (int rnd = 0; rnd < CORR_TB / 2048; ++rnd) {
+        unsigned long long packed = 0;
+        const long long o0 = i0 + 2048ll * rnd + 8 * t;
+        if (o0 >= n) break;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long i = o0 + j;
+            unsigned o = 0;
+            if (i < n) {
+                // bit 0: stream bit i-64
+                long long b = i - 64;
+                long long w = b >> 6;                          // floor division (arithmetic shift)
+                int r = (int)(b & 63);
+                o |= (unsigned)((corr_word(P, w, wlo, st.data_reg) >> (63 - r)) & 1ull);
+                // bit 1: flags already in flight at call start
+                if (i < 64) o |= (unsigned)((st.flag_reg >> (63 - i)) & 1ull) << 1;
+                // bit 1: flag computed len items ago
+                long long k = i - (long long)p.len;
+                if (k >= 0 && p.len > 0) {
+                    long long wk = k >> 6;
+                    int rk = (int)(k & 63);
+                    unsigned long long hi = corr_word(P, wk - 1, wlo, st.data_reg);
+                    unsigned long long W = hi;
+                    if (rk) W = (hi << rk) | (corr_word(P, wk, wlo, st.data_reg) >> (64 - rk));
+                    unsigned nwrong = (unsigned)__popcll((W ^ p.access_code) & p.mask);
+                    if (nwrong <= p.threshold) o |= 2u;
+                }
+            }
+            packed |= (unsigned long long)o << (8 * j);
+        }
+        if (o0 + 8 <= n && ((((uintptr_t)(y + o0)) & 7) == 0)) {
+            *reinterpret_cast<unsigned long long *>(y + o0) = packed;
+        } else {
+            for (int j = 0; j < 8; ++j)
+                if (o0 + j < n) y[o0 + j] = (unsigned char)(packed >> (8 * j));
+        }
     }
 }
 

@@ -214,10 +214,157 @@ pfb_kernel(const PfbArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fast path of the channeliser: oversample_rate 1 (rate_ratio == M), M a power of two
+// <= 16.  Then output vector t applies filter M-1-j to stream j at in_j[t+1 ...] and
+// the result goes to IFFT slot M-1-j, for every t: M independent real-tap FIRs
+// followed by an M-point backward DFT.
+//   * wave j of a 64*M-lane workgroup owns stream j for a tile of 512 output vectors:
+//     it stages its own 512+tpf samples in LDS (coalesced 16-byte loads, one pad slot
+//     per 8 samples -> conflict-free ds_read_b64) and runs the FIR with 8 outputs per
+//     lane, an 8-deep register window and the (wave-uniform) taps in SGPRs -- the same
+//     inner structure as fir_tiled_kernel;
+//   * the filtered samples go back to LDS transposed (slot-major), one barrier, and
+//     each lane then finishes one output vector with an in-register radix-2 FFT and
+//     writes M contiguous complex values.
+// 16 B of HBM traffic per input sample, HBM-bound (about 9 flop/B).
+// ---------------------------------------------------------------------------
+typedef const float __attribute__((address_space(4))) *pfb_cfloat_p;
+
+template <int M>
+__global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a)
+{
+    constexpr int R = 8, TT = 64 * R;                  // output vectors per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tpfp = (a.tpf + R - 1) / R * R;          // taps padded to a multiple of R (zeros)
+    const int XS = (TT + tpfp + R) + (TT + tpfp + R) / R + 1;   // slots per stream, padded
+    const int SS = TT + TT / R + 1;                    // slots per IFFT input row, padded
+    float2 *xs = (float2 *)smem;                       // [M][XS]
+    float2 *sl = xs + (size_t)M * XS;                  // [M][SS]
+    const int t = threadIdx.x, j = t >> 6, ln = t & 63;
+    const long long t0 = (long long)blockIdx.x * TT;
+    const pfb_cfloat_p taps = (pfb_cfloat_p)(a.ftaps) + (size_t)(M - 1 - j) * a.tpf;
+    const pfb_cfloat_p dft = (pfb_cfloat_p)(a.dft);
+
+    // ---- stage stream j: items in_j[t0+1 .. t0+TT+tpfp]; readable range is [0, nout+tpf]
+    {
+        const float2 *x = a.in + (long long)j * a.stride;
+        const long long lim = a.nout + a.tpf;          // tpf history items + nout new ones per stream
+        float2 *dst = xs + (size_t)j * XS;
+        for (int m = ln; m < TT + tpfp; m += 64) {
+            const long long g = t0 + 1 + m;
+            dst[m + (m >> 3)] = (g < lim) ? x[g] : make_float2(0.f, 0.f);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);                     // wave-private region: no workgroup barrier needed
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- FIR, 8 output vectors per lane
+    float2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
+    {
+        const float2 *xp = xs + (size_t)j * XS + ln * R + ln;      // slot of m = 8 ln
+        float2 w[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) w[q] = xp[q];
+        for (int q0 = 0; q0 < tpfp; q0 += R) {
+            const int nxt = q0 + R + (q0 >> 3) + 1;
+#pragma unroll
+            for (int qq = 0; qq < R; ++qq) {
+                const float h = (q0 + qq < a.tpf) ? taps[q0 + qq] : 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float2 xv = w[(qq + r) & (R - 1)];
+                    acc[r].x = __builtin_fmaf(h, xv.x, acc[r].x);
+                    acc[r].y = __builtin_fmaf(h, xv.y, acc[r].y);
+                }
+                w[qq] = xp[nxt + qq];
+            }
+        }
+    }
+    // ---- to IFFT slot M-1-j, transposed: sl[slot][t_local]
+    {
+        float2 *row = sl + (size_t)(M - 1 - j) * SS + ln * R + ln;
+#pragma unroll
+        for (int r = 0; r < R; ++r) row[r] = acc[r];
+    }
+    __syncthreads();
+
+    // ---- M-point backward DFT (unnormalised), one output vector per lane
+    for (int tl = t; tl < TT; tl += 64 * M) {
+        const long long tt = t0 + tl;
+        if (tt >= a.nout) continue;
+        float2 v[M];
+        // bit-reversed load, then radix-2 decimation-in-time stages
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            int rv = 0;
+#pragma unroll
+            for (int b = 1, c = M >> 1; b < M; b <<= 1, c >>= 1) if (s & b) rv |= c;
+            v[rv] = sl[(size_t)s * SS + tl + (tl >> 3)];
+        }
+#pragma unroll
+        for (int len = 2; len <= M; len <<= 1) {
+            const int half = len >> 1, step = M / len;
+#pragma unroll
+            for (int s0 = 0; s0 < M; s0 += len) {
+#pragma unroll
+                for (int k = 0; k < half; ++k) {
+                    const float wr = dft[2 * (k * step)], wi = dft[2 * (k * step) + 1];   // e^{+2 pi i k/len}
+                    const float2 u = v[s0 + k], q = v[s0 + k + half];
+                    const float2 tw = (k == 0) ? q : make_float2(__builtin_fmaf(q.x, wr, -(q.y * wi)),
+                                                                 __builtin_fmaf(q.x, wi, q.y * wr));
+                    v[s0 + k] = make_float2(u.x + tw.x, u.y + tw.y);
+                    v[s0 + k + half] = make_float2(u.x - tw.x, u.y - tw.y);
+                }
+            }
+        }
+        float2 *o = a.out + tt * M;
+        if (M >= 2) {
+            float4 *o4 = reinterpret_cast<float4 *>(o);
+#pragma unroll
+            for (int k = 0; k < M; k += 2) o4[k >> 1] = make_float4(v[k].x, v[k].y, v[k + 1].x, v[k + 1].y);
+        } else {
+            o[0] = v[0];
+        }
+    }
+}
+
+template <int M>
+static int launch_pfb_os1(const PfbArgs &a, hipStream_t st)
+{
+    const int R = 8, TT = 512;
+    const int tpfp = (a.tpf + R - 1) / R * R;
+    const int XS = (TT + tpfp + R) + (TT + tpfp + R) / R + 1;
+    const int SS = TT + TT / R + 1;
+    size_t lds = ((size_t)M * XS + (size_t)M * SS) * sizeof(float2);
+    if (lds > 150 * 1024) return -1;
+    static size_t cfg = 0;
+    if (lds > 48 * 1024 && lds > cfg) {
+        GRHIP_HIP(hipFuncSetAttribute((const void *)pfb_os1_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+        cfg = lds;
+    }
+    hipLaunchKernelGGL(pfb_os1_kernel<M>, dim3((unsigned)((a.nout + TT - 1) / TT)), dim3(64 * M), lds, st, a);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
 int launch_pfb(const PfbArgs &a, hipStream_t st)
 {
     if (a.nout <= 0) return GRHIP_OK;
     if (a.M < 1 || a.M > 1024) return fail(GRHIP_EINVAL, "numchans %d not supported on device", a.M);
+    if (a.rate_ratio == a.M && (((uintptr_t)a.out) & 15) == 0) {
+        int rc = -1;
+        switch (a.M) {
+        case 2: rc = launch_pfb_os1<2>(a, st); break;
+        case 4: rc = launch_pfb_os1<4>(a, st); break;
+        case 8: rc = launch_pfb_os1<8>(a, st); break;
+        case 16: rc = launch_pfb_os1<16>(a, st); break;
+        }
+        if (rc != -1) return rc;
+    }
     int ty = 256 / a.M; if (ty < 1) ty = 1;
     dim3 block(a.M, ty);
     dim3 grid((unsigned)((a.nout + ty - 1) / ty));

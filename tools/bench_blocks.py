@@ -1,0 +1,96 @@
+"""Secondary measurements (not the headline line): every other block of SURVEY 8(a)
+at its BASELINE size on one GPU, device-resident, as algorithmic GB/s against the
+8 TB/s HBM peak.  usage: python tools/bench_blocks.py"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import grhip_loader
+
+g = grhip_loader.import_grhip()
+wl = g.workload
+dev = torch.device("cuda", 0)
+st = torch.cuda.Stream(device=dev)
+PEAK = 8000.0
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    st.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        fn()
+    e1.record(st)
+    st.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def report(name, ms, items, bytes_per_item, unit="Msamples/s"):
+    gbs = items * bytes_per_item / (ms * 1e-3) / 1e9
+    print(json.dumps({"block": name, "ms": round(ms, 4), "rate": round(items / ms / 1e3, 1), "unit": unit,
+                      "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK, 4)}), flush=True)
+
+
+rng = np.random.default_rng(0)
+
+# cfg1: fir_filter_ccf 64 taps, D=1, 1 M samples (and 16 M to get out of launch-latency land)
+for n in (1_000_000, 16_000_000):
+    x = torch.randn((n + 64, 2), device=dev)
+    y = torch.empty((n, 2), device=dev)
+    blk = g.fir_filter_ccf(1, wl.lowpass_taps(64, 0.1, 1.0))
+    report("fir_filter_ccf 64t D=1 n=%d" % n, timeit(lambda: blk.work_device(n, x, y, st)), n, 16)
+
+# published-baseline shape: fir_filter_fff 256 taps D=1 (generic-order kernel, bit-exact)
+n = 16_000_000
+xf = torch.randn(n + 256, device=dev)
+yf = torch.empty(n, device=dev)
+blk = g.fir_filter_fff(1, wl.lowpass_taps(256, 0.1, 1.0))
+report("fir_filter_fff 256t D=1 (generic order)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=5), n, 8)
+
+# unfused xlating (10 B / input sample) and quad_demod (12 B / item)
+n = 10_000_000
+c = wl.CFG2
+x = torch.randn((n + 256, 2), device=dev)
+y = torch.empty((n // 4, 2), device=dev)
+blk = g.freq_xlating_fir_filter_ccc(4, wl.cfg2_proto_taps(), c["center_freq"], c["fs"])
+def run_xl():
+    blk.reset(); blk.work_device(n // 4, x, y, st)
+report("freq_xlating_fir_filter_ccc 256t D=4", timeit(run_xl), n, 10)
+cp = (wl.cfg2_proto_taps() * np.exp(1j * 0.01 * np.arange(256))).astype(np.complex64)
+blk2 = g.freq_xlating_fir_filter_ccc(4, cp, c["center_freq"], c["fs"])
+def run_xl2():
+    blk2.reset(); blk2.work_device(n // 4, x, y, st)
+report("freq_xlating_fir_filter_ccc 256 COMPLEX taps D=4", timeit(run_xl2), n, 10)
+d = torch.empty(n, device=dev)
+xx = torch.randn((n + 1, 2), device=dev)
+qd = g.quadrature_demod_cf(1.0)
+report("quadrature_demod_cf", timeit(lambda: qd.work_device(n, xx, d, st)), n, 12)
+
+# correlator (2 B / bit)
+n = 64_000_000
+bits = torch.randint(0, 2, (n,), dtype=torch.uint8, device=dev)
+ob = torch.empty(n, dtype=torch.uint8, device=dev)
+ca = g.correlate_access_code_bb(wl.access_code_string(), 4)
+report("correlate_access_code_bb", timeit(lambda: ca.work_device(n, bits, ob, st)), n, 2, "Mbits/s")
+
+# cfg3: fft_vcc 4096-pt over 2^24 samples; pfb_channelizer M=8, 256-tap prototype, 2^24 samples
+N, nvec = 4096, 4096
+xv = torch.randn((N * nvec, 2), device=dev)
+yv = torch.empty((N * nvec, 2), device=dev)
+ff = g.fft_vcc(N, True, [], False)
+report("fft_vcc 4096-pt x 4096", timeit(lambda: ff.work_device(nvec, xv, yv, st)), N * nvec, 16)
+M, nout = 8, (1 << 24) // 8
+taps = wl.lowpass_taps(256, 0.5 / M, 1.0)
+pf = g.pfb_channelizer_ccf(M, taps, 1.0)
+per = nout + 64
+xs = torch.randn((M * per, 2), device=dev)
+yo = torch.empty((nout * M, 2), device=dev)
+pf.general_work_device(nout, xs, per, yo, st)       # first call returns 0 (d_updated)
+report("pfb_channelizer_ccf M=8 256t", timeit(lambda: pf.general_work_device(nout, xs, per, yo, st)), nout * M, 16)
