@@ -4,7 +4,7 @@ properties at the BASELINE size."""
 import numpy as np
 import pytest
 
-from conftest import bits_equal, rel_err_max
+from conftest import bits_equal, demod_close, rel_err_max
 
 pytestmark = pytest.mark.gpu
 
@@ -68,7 +68,8 @@ def test_chain_three_streams_vs_oracle(gpu, po, wl):
                 assert bits_equal(dem, dem_ref)
                 assert bits_equal(soft, soft_ref)
             else:
-                assert rel_err_max(dem, dem_ref) <= 1e-5
+                ok, worst = demod_close(dem, dem_ref)
+                assert ok, worst
                 # M&M quantises mu to 1/128 sample (rint(mu*128),
                 # gri_mmse_fir_interpolator.cc:64): a 1e-6 input difference can
                 # pick the neighbouring interpolator phase for one symbol, which

@@ -5,7 +5,7 @@ CPU oracle.  Tolerances: GENERIC mode bit-exact; FAST mode 1e-5 relative
 import numpy as np
 import pytest
 
-from conftest import bits_equal, rel_err_max
+from conftest import bits_equal, demod_close, rel_err_max
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -237,14 +237,16 @@ def test_fused_xlating_demod_cfg2(gpu, po, wl):
     xin = wl.with_history(x, 255)
     blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
     got = blk.work(nout, xin)
-    assert rel_err_max(got, ref) <= TOL
+    ok, worst = demod_close(got, ref)
+    assert ok, worst
     # generic mode: FIR+rotator bit exact, demod bit exact => whole chain bit exact
     blk.reset(); blk.set_mode(gpu.MODE_GENERIC)
     assert bits_equal(blk.work(nout, xin), ref)
     # chunked fast: demodulator's previous sample carried across calls
     blk.reset(); blk.set_mode(gpu.MODE_FAST)
     got2 = gpu.run_sync_block(blk, x, chunk=8192)
-    assert rel_err_max(got2, ref) <= TOL
+    ok, worst = demod_close(got2, ref)
+    assert ok, worst
 
 
 def test_unfused_pipeline_equals_fused(gpu, po, wl):
@@ -260,7 +262,8 @@ def test_unfused_pipeline_equals_fused(gpu, po, wl):
     d = qd.work(nout, wl.with_history(y, 1))
     fused = gpu.xlating_demod(4, proto, c["center_freq"], c["fs"], c["demod_gain"]).work(nout, wl.with_history(x, 255))
     # only the tile-boundary predecessor differs (tree-order sum): well inside tolerance
-    assert rel_err_max(d, fused) <= 2e-6
+    ok, worst = demod_close(d, fused, tol=4e-6)
+    assert ok, worst
 
 
 def test_errors_and_edges(gpu):
