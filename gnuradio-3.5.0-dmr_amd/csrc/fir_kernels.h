@@ -37,7 +37,6 @@ struct FirTiledArgs {
     float2 *y_last;         // EPI 2: [n_streams] receives the last y of this call (distinct buffer)
     const float *atan_tab;  // EPI 2
     int vec_store;          // 1 if output rows are 16-byte aligned
-    int stagger;            // cycles the second workgroup of every CU idles before its first tile
     int ablate;             // profiling only (env GRHIP_ABLATE): 1 skip global loads, 2 skip MAC loop, 4 skip demod math
 };
 

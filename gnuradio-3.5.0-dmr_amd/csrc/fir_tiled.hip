@@ -278,14 +278,6 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         if (s >= a.n_streams) { s -= a.n_streams; ++b; }
     };
     int s = (int)(blockIdx.x % (unsigned)a.n_streams), bidx = (int)(blockIdx.x / (unsigned)a.n_streams);
-    // The workgroups that share a CU run identical phases; left alone they sit in the
-    // same phase at the same time (both in the MAC loop, or both waiting on memory).
-    // The later-dispatched half idles once for part of a tile so that one's MAC loop
-    // overlaps the other's staging / epilogue.  Speed only: any placement is correct.
-    if (a.stagger > 0 && blockIdx.x >= (gridDim.x + 1) / 2) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(8);
-    }
     if (bidx < tiles_per_stream) { fetch_phases(bidx); fetch(s, bidx); }
     STAMP_DECL;
 
@@ -545,9 +537,6 @@ int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiled
     static int ablate = -1;
     if (ablate < 0) { const char *e = getenv("GRHIP_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
-    static int stagger = -1;
-    if (stagger < 0) { const char *e = getenv("GRHIP_STAGGER"); stagger = e ? atoi(e) : 8000; }   // measured: 3 % on cfg2
-    a.stagger = stagger;
     switch (decim) {
     case 1: return launch_tiled_d<1>(ctaps, premix, epi, a, st);
     case 2: return launch_tiled_d<2>(ctaps, premix, epi, a, st);
