@@ -252,10 +252,12 @@ struct grhip_fir_filter : HandleBase {
         int rc = upload(d_taps_rev, rev.data(), rev.size() * sizeof(float));
         if (rc) return rc;
         use_tiled = false;
-        if (kind != FIR_FFF && ntaps > 0) {
+        if (ntaps > 0 && (kind != FIR_FFF || decim <= 2)) {
+            // float data runs the complex kernel on overlapped pairs at twice the decimation
+            const int dk = kind == FIR_FFF ? 2 * decim : decim;
             std::vector<float> hp;
-            Tq = pack_phase_major(rev.data(), ntaps, tw(), decim, hp);
-            if (tiled_supported(decim, Tq)) {
+            Tq = pack_phase_major(rev.data(), ntaps, tw(), dk, hp);
+            if (tiled_supported(dk, Tq)) {
                 rc = upload(d_hp, hp.data(), hp.size() * sizeof(float));
                 if (rc) return rc;
                 use_tiled = true;
@@ -267,14 +269,21 @@ struct grhip_fir_filter : HandleBase {
     int run(const void *d_in, void *d_out, long long n, int dec, hipStream_t st)
     {
         if (n <= 0) return GRHIP_OK;
-        if (mode == GRHIP_MODE_FAST && use_tiled && dec == decim) {
+        if (mode == GRHIP_MODE_FAST && use_tiled && dec == decim && (kind != FIR_FFF || n >= 2)) {
             FirTiledArgs a;
             memset(&a, 0, sizeof(a));
             a.x = (const float2 *)d_in; a.n_in = (n - 1) * dec + ntaps;
             a.hp = d_hp.as<float>(); a.Tq = Tq; a.n_out = n;
             a.y_out = (float2 *)d_out;
             a.vec_store = (((uintptr_t)d_out) & 15) == 0;
-            return launch_fir_tiled(dec, kind == FIR_CCC, false, EPI_NONE, a, 1, st);
+            if (kind != FIR_FFF) return launch_fir_tiled(dec, kind == FIR_CCC, false, EPI_NONE, a, 1, st);
+            // gr_fir_fff: output pairs (y[2j], y[2j+1]); an odd last output goes through the generic kernel
+            a.fpair = dec;
+            a.n_out = n / 2;
+            int rc = launch_fir_tiled(2 * dec, false, false, EPI_NONE, a, 1, st);
+            if (rc || !(n & 1)) return rc;
+            return launch_fir_generic(kind, d_taps_rev.as<float>(), ntaps, (const float *)d_in + (n - 1) * dec,
+                                      (float *)d_out + (n - 1), 1, dec, nullptr, st);
         }
         return launch_fir_generic(kind, d_taps_rev.as<float>(), ntaps, d_in, d_out, n, dec, nullptr, st);
     }

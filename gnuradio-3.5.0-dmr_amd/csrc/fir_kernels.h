@@ -37,6 +37,7 @@ struct FirTiledArgs {
     float2 *y_last;         // EPI 2: [n_streams] receives the last y of this call (distinct buffer)
     const float *atan_tab;  // EPI 2
     int vec_store;          // 1 if output rows are 16-byte aligned
+    int fpair;              // 0: complex items; 1/2: float-pair mode of gr_fir_fff with that decimation
     int ablate;             // profiling only (env GRHIP_ABLATE): 1 skip global loads, 2 skip MAC loop, 4 skip demod math
 };
 

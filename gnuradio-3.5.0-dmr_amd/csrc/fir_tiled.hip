@@ -117,9 +117,15 @@ __device__ __forceinline__ float wave_sum(float x)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
-template <int D, bool CTAPS, bool PREMIX, int EPI>
+// FP > 0: float-pair mode for gr_fir_fff.  A float FIR with decimation FP is the
+// complex-data kernel with decimation D = 2 FP run on the overlapped pair stream
+// z[m] = (x[m], x[m+FP]):  sum_k c[k] z[nD + k] = (y[2n], y[2n+1]).  The pair stream is
+// never materialised: each lane loads 16 bytes (4 floats) at an 8-byte lane stride and
+// forms its two items while staging; the outputs land in a plain float array.
+template <int D, bool CTAPS, bool PREMIX, int EPI, int FP = 0>
 __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kernel(const FirTiledArgs a)
 {
+    static_assert(FP == 0 || (D == 2 * FP && !CTAPS && !PREMIX && EPI == EPI_NONE), "float-pair mode");
     constexpr int R = TILED_R, LOGR = TILED_LOGR, NT = TILED_NT, NI = TILED_NI;
     constexpr int LOGD = ilog2(D);
     constexpr int TW = CTAPS ? 2 : 1;               // floats per tap
@@ -193,14 +199,24 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     // zeros from the hardware range check (per dword), so there is no bounds code.
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int LANE_BYTES = FP ? 8 : 16;         // bytes between the loads of neighbouring lanes
     auto tile_geom = [&](int s, int b, __amdgpu_buffer_rsrc_t &rsrc, int &voff, int &off) {
+        const long long g0 = ((long long)b * NT - 1) * D - a.n_lo;        // tile start relative to the first real item
+        if (FP) {
+            // items are floats; strides and counts of the launch are in floats
+            const float *xf = reinterpret_cast<const float *>(a.x) + (long long)s * a.x_stride + a.n_lo;
+            off = 0;
+            const long long bytes = (a.ablate & 1) ? 0 : (a.n_in - a.n_lo) * 4;
+            rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xf), 0, (int)bytes, 0x00020000);
+            voff = (int)(g0 * 4) + LANE_BYTES * t;
+            return;
+        }
         const float2 *x = a.x + (long long)s * a.x_stride + a.n_lo;       // first real item
-        const long long g0 = ((long long)b * NT - 1) * D - a.n_lo;        // tile start relative to it
         const long long unit0 = (long long)(((unsigned long long)(uintptr_t)x) >> 3) + g0;
         off = (int)(unit0 & 1);                     // pair starts on a 16-byte boundary
         const long long bytes = (a.ablate & 1) ? 0 : (a.n_in - a.n_lo) * 8;
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x), 0, (int)bytes, 0x00020000);
-        voff = (int)((g0 - off) * 8) + 16 * t;      // may be negative: out of range => zeros
+        voff = (int)((g0 - off) * 8) + LANE_BYTES * t;      // may be negative: out of range => zeros
     };
 
     // ---- rotator phases of a tile's outputs (issued at the end of the previous tile:
@@ -229,7 +245,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         tile_geom(s, b, rsrc, voff, off);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + i * (16 * TILED_THREADS), 0, 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + i * (LANE_BYTES * TILED_THREADS), 0, 0);
             const f32x4 f = __builtin_bit_cast(f32x4, v);
             pf[i] = make_float4(f[0], f[1], f[2], f[3]);
         }
@@ -258,6 +274,8 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
             const int u = ub + 2 * TILED_THREADS * i;
             if (u < Lu) {
                 float2 e0 = make_float2(pf[i].x, pf[i].y), e1 = make_float2(pf[i].z, pf[i].w);
+                if (FP == 1) { e0 = make_float2(pf[i].x, pf[i].y); e1 = make_float2(pf[i].y, pf[i].z); }   // (x[u],x[u+1]), (x[u+1],x[u+2])
+                if (FP == 2) { e0 = make_float2(pf[i].x, pf[i].z); e1 = make_float2(pf[i].y, pf[i].w); }   // (x[u],x[u+2]), (x[u+1],x[u+3])
                 if (PREMIX) {
                     const float2 si = make_float2(sv[2 * i], sv[2 * i + 1]);
                     e0 = cmul_fma(e0, cmul_fma(w0l, si));
@@ -471,11 +489,11 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
 
 static int g_num_cus = 0;
 
-template <int D, bool CTAPS, bool PREMIX, int EPI>
+template <int D, bool CTAPS, bool PREMIX, int EPI, int FP = 0>
 static int launch_tiled_inst(const FirTiledArgs &a, hipStream_t st)
 {
     size_t lds = tiled_lds_bytes(D, a.Tq);
-    auto kern = fir_tiled_kernel<D, CTAPS, PREMIX, EPI>;
+    auto kern = fir_tiled_kernel<D, CTAPS, PREMIX, EPI, FP>;
     static size_t configured = 0;   // per instantiation
     if (lds > 48 * 1024 && lds > configured) {
         GRHIP_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -514,6 +532,11 @@ static int launch_tiled_d(bool ctaps, bool premix, int epi, const FirTiledArgs &
         }
     }
     if (epi != EPI_NONE) return fail(GRHIP_EINVAL, "real taps without premix have no rotator");
+    if (a.fpair) {
+        if constexpr (D == 2) { if (a.fpair == 1) return launch_tiled_inst<2, false, false, EPI_NONE, 1>(a, st); }
+        if constexpr (D == 4) { if (a.fpair == 2) return launch_tiled_inst<4, false, false, EPI_NONE, 2>(a, st); }
+        return fail(GRHIP_EINVAL, "float-pair mode needs decimation 1 or 2");
+    }
     return launch_tiled_inst<D, false, false, EPI_NONE>(a, st);
 }
 

@@ -274,3 +274,26 @@ def test_errors_and_edges(gpu):
     assert len(blk.work(0, np.zeros(0, np.complex64))) == 0
     out = blk.work(5, np.ones(5, np.complex64))          # zero taps -> zeros
     assert np.array_equal(out, np.zeros(5, np.complex64))
+
+
+@pytest.mark.parametrize("ntaps,decim,n", [(1, 1, 9), (3, 1, 4097), (256, 1, 100_001), (255, 2, 50_000), (64, 2, 33_333),
+                                           (17, 1, 2), (300, 4, 5000)])
+def test_fir_fff_fast_mode(gpu, po, ntaps, decim, n):
+    """gr_fir_filter_fff through the tiled kernel's float-pair mode (decimation 1, 2;
+    decimation 4 falls back to the generic-order kernel), odd output counts included"""
+    rng = np.random.default_rng(ntaps * 7 + decim)
+    nin = n * decim + ntaps - 1
+    x = rng.uniform(-1, 1, nin).astype(np.float32)
+    taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+    blk = gpu.fir_filter_fff(decim, taps)
+    blk.set_mode(gpu.MODE_FAST)
+    got = blk.work(n, x)
+    ref = po.fir_fff(taps, x, n, decim)
+    bound = np.abs(taps).sum()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3 * bound)
+    # integer-valued data: exact in any order
+    xi = rng.integers(-8, 8, nin).astype(np.float32)
+    ti = rng.integers(-4, 4, ntaps).astype(np.float32)
+    blk2 = gpu.fir_filter_fff(decim, ti)
+    assert np.array_equal(blk2.work(n, xi), po.fir_fff(ti, xi, n, decim))

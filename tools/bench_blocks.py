@@ -47,12 +47,14 @@ for n in (1_000_000, 16_000_000):
     blk = g.fir_filter_ccf(1, wl.lowpass_taps(64, 0.1, 1.0))
     report("fir_filter_ccf 64t D=1 n=%d" % n, timeit(lambda: blk.work_device(n, x, y, st)), n, 16)
 
-# published-baseline shape: fir_filter_fff 256 taps D=1 (generic-order kernel, bit-exact)
+# published-baseline shape (mp-sched, fir_filter_fff 256 taps, decimation 1)
 n = 16_000_000
 xf = torch.randn(n + 256, device=dev)
 yf = torch.empty(n, device=dev)
 blk = g.fir_filter_fff(1, wl.lowpass_taps(256, 0.1, 1.0))
-report("fir_filter_fff 256t D=1 (generic order)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=5), n, 8)
+report("fir_filter_fff 256t D=1 FAST (tiled kernel, float-pair mode)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=5), n, 8)
+blk.set_mode(g.MODE_GENERIC)
+report("fir_filter_fff 256t D=1 GENERIC (bit-exact order)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=5), n, 8)
 
 # unfused xlating (10 B / input sample) and quad_demod (12 B / item)
 n = 10_000_000
