@@ -91,7 +91,7 @@ int XlatingCore::build(int device)
                 W[v + 1] = cf((float)cos(ang), (float)sin(ang));
             }
             for (int i = 0; i < (int)S.size(); ++i) {
-                double ang = omega * 512.0 * (double)i;
+                double ang = omega * (double)tiled_load_span() * (double)i;
                 S[i] = cf((float)cos(ang), (float)sin(ang));
             }
             for (int j = 0; j < NT; ++j) {
@@ -167,6 +167,19 @@ int XlatingCore::ensure_rot(long long n, const float2 **gtab)
     return GRHIP_OK;
 }
 
+// rotator phase of output pos-1 (for converting the demodulator carry between the
+// frames of the two epilogues at a mode switch): phase(pos) * conj(incr)
+int XlatingCore::phase_before_pos(std::complex<float> *g)
+{
+    const float2 *gtab = nullptr;
+    int rc = ensure_rot(1, &gtab);
+    if (rc) return rc;
+    cf ph;
+    GRHIP_HIP(hipMemcpy(&ph, gtab, sizeof(ph), hipMemcpyDeviceToHost));
+    *g = ph * std::conj(incr);
+    return GRHIP_OK;
+}
+
 void XlatingCore::release()
 {
     d_taps_generic.release(); d_hp.release(); d_wtab.release(); d_stab.release(); d_vtab.release(); d_rot.release();
@@ -182,9 +195,13 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
 {
     if (n_out <= 0) return GRHIP_OK;
     const float2 *gtab = nullptr;
-    int rc = ensure_rot(n_out, &gtab);
-    if (rc) return rc;
     const bool demod = d_demod != nullptr;
+    const bool direct = demod_is_direct(mode, demod);
+    int rc = GRHIP_OK;
+    if (!direct) {          // the direct demodulator epilogue needs no rotator phases
+        rc = ensure_rot(n_out, &gtab);
+        if (rc) return rc;
+    }
     if (mode == GRHIP_MODE_FAST && use_tiled) {
         FirTiledArgs a;
         memset(&a, 0, sizeof(a));
@@ -196,7 +213,8 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         a.y_prev = y_prev; a.y_last = y_last; a.atan_tab = atan_tab;
         uintptr_t o = demod ? (uintptr_t)d_demod : (uintptr_t)d_y;
         a.vec_store = (o & 15) == 0 && ((out_stride * (demod ? 4 : 8)) & 15) == 0;
-        rc = launch_fir_tiled(decim, !premix, premix, demod ? EPI_ROTATE_DEMOD : EPI_ROTATE, a, n_streams, st);
+        rc = launch_fir_tiled(decim, !premix, premix, direct ? EPI_DEMOD : demod ? EPI_ROTATE_DEMOD : EPI_ROTATE, a,
+                              n_streams, st);
         if (rc) return rc;
     } else {
         if (n_streams != 1 || n_lo != 0)
@@ -439,6 +457,7 @@ struct grhip_xlating_demod : HandleBase {
                      // sample, [2] constant zero (the history item of a fresh block)
     int cur = 0;
     bool fresh = true;
+    bool carry_direct = false;   // frame of the carried sample (fir_kernels.h, EPI_DEMOD)
 };
 
 static int xlating_args_ok(int decimation, const float *taps, size_t ntaps, double sampling_freq)
@@ -704,6 +723,17 @@ int grhip_xlating_demod_work_device(grhip_xlating_demod *h, int noutput_items, c
     long long n = noutput_items;
     long long n_in = (n - 1) * h->core.decim + h->core.ntaps;
     float2 *ys = h->ystate.as<float2>();
+    const bool direct = h->core.demod_is_direct(h->mode, true);
+    if (!h->fresh && direct != h->carry_direct) {
+        // mode switch in mid-stream: move the one-sample carry into the other epilogue's frame
+        cf g, y;
+        if ((rc = h->core.phase_before_pos(&g))) return rc;
+        GRHIP_HIP(hipStreamSynchronize(h->pick(stream)));
+        GRHIP_HIP(hipMemcpy(&y, ys + h->cur, sizeof(y), hipMemcpyDeviceToHost));
+        y = direct ? y * std::conj(g) : y * g;
+        GRHIP_HIP(hipMemcpy(ys + h->cur, &y, sizeof(y), hipMemcpyHostToDevice));
+    }
+    h->carry_direct = direct;
     rc = h->core.run(h->mode, (const float2 *)d_in, n_in, n, nullptr, (float *)d_out, h->gain,
                      h->fresh ? ys + 2 : ys + h->cur, ys + (h->cur ^ 1), h->tabs->atan_tab, h->pick(stream));
     if (rc) return rc;
@@ -724,7 +754,7 @@ int grhip_xlating_demod_run_captures_device(grhip_xlating_demod *h, int n_stream
     if (n_out <= 0) return GRHIP_OK;
     if (!(h->mode == GRHIP_MODE_FAST && h->core.use_tiled))
         return fail(GRHIP_EINVAL, "run_captures needs the tiled path (FAST mode, supported decimation)");
-    if (h->core.tab_start != 0)
+    if (h->core.tab_start != 0 && !h->core.demod_is_direct(GRHIP_MODE_FAST, true))
         return fail(GRHIP_EINVAL, "handle has streamed past its cached rotator table; use a fresh handle");
     const long long hist = h->core.ntaps > 0 ? h->core.ntaps - 1 : 0;
     const long long keep = h->core.pos;

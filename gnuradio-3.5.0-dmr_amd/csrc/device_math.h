@@ -24,7 +24,9 @@ __device__ __forceinline__ float2 cmul_fma(float2 a, float2 b)
 // gr_fast_atan2f (gnuradio-core/src/lib/general/gr_fast_atan2f.cc:125-198).
 // REAL = float but the literals are double: the comparisons and the "- .5"
 // are evaluated in double and narrowed on assignment, as written there.
-__device__ __forceinline__ float fast_atan2f(float y, float x, const float *__restrict__ tab)
+// `tab` is anything indexable with 0..256: a pointer, or a view of a table stored with gaps
+template <class Tab>
+__device__ __forceinline__ float fast_atan2f(float y, float x, Tab tab)
 {
     float x_abs, y_abs, z;
     float alpha, angle, base_angle;
@@ -79,8 +81,8 @@ __device__ __forceinline__ float fast_atan2f(float y, float x, const float *__re
 }
 
 // one output of gr_quadrature_demod_cf::work (general/gr_quadrature_demod_cf.cc:57-59)
-__device__ __forceinline__ float quad_demod_one(float2 cur, float2 prev, float gain,
-                                                const float *__restrict__ tab)
+template <class Tab>
+__device__ __forceinline__ float quad_demod_one(float2 cur, float2 prev, float gain, Tab tab)
 {
     float2 product = cmul_ref(cur, make_float2(prev.x, -prev.y));   // in[i] * conj(in[i-1])
     return gain * fast_atan2f(product.y, product.x, tab);

@@ -27,10 +27,10 @@ struct FirTiledArgs {
     const float2 *stab;     // PREMIX: stab[i] = e^{jw 512 i}, i < tiled_stab_len()
     const float2 *vtab;     // PREMIX: vtab[j] = e^{-jw j D}, j < NT; vtab[NT] = e^{+jwD} (boundary output)
     int n_streams;          // filled in by launch_fir_tiled
-    const float2 *gtab;     // EPI>=1: rotator phase per output of this call (stream-independent)
+    const float2 *gtab;     // EPI 1/2: rotator phase per output of this call (stream-independent)
     float2 *y_out;          // EPI 0/1
     long long y_stride;
-    float *d_out;           // EPI 2
+    float *d_out;           // EPI 2/3
     long long d_stride;
     float gain;             // EPI 2
     const float2 *y_prev;   // EPI 2: [n_streams] y[-1] carried in from the previous call
@@ -38,10 +38,16 @@ struct FirTiledArgs {
     const float *atan_tab;  // EPI 2
     int vec_store;          // 1 if output rows are 16-byte aligned
     int fpair;              // 0: complex items; 1/2: float-pair mode of gr_fir_fff with that decimation
-    int ablate;             // profiling only (env GRHIP_ABLATE): 1 skip global loads, 2 skip MAC loop, 4 skip demod math
+    int skew_mode, skew_sleeps;   // start-up skew between the workgroups sharing a CU (filled in by the launcher)
+    int ablate;             // profiling only (env GRHIP_ABLATE): 1 skip global loads, 4 skip demod math
 };
 
-enum { EPI_NONE = 0, EPI_ROTATE = 1, EPI_ROTATE_DEMOD = 2 };
+// EPI_DEMOD (pre-mix form only): the demodulator works on the pre-mixed accumulators
+// directly.  y[n] conj(y[n-1]) = acc[n] conj(acc[n-1]) * (v[j] conj(v[j-1])) * (g[n] conj(g[n-1]))
+// and the last two factors are e^{-jwD} and the rotator step e^{+jwD}(1 + O(1e-7)), so neither
+// the phase correction nor the rotator table is needed; the carry (y_prev / y_last) is kept
+// in the frame of the un-rotated composite FIR output, acc * v.
+enum { EPI_NONE = 0, EPI_ROTATE = 1, EPI_ROTATE_DEMOD = 2, EPI_DEMOD = 3 };
 
 // returns GRHIP_OK or <0 ; `decim` must be one of tiled_supported_decim().
 bool tiled_supported(int decim, int ntaps_padded_per_phase);
@@ -49,6 +55,7 @@ int tiled_R();                      // outputs per lane
 int tiled_NT();                     // outputs per workgroup tile
 int tiled_wtab_len();
 int tiled_stab_len();
+int tiled_load_span();              // samples covered by one round of 16-byte loads of a workgroup
 int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiledArgs &a,
                      int n_streams, hipStream_t st);
 

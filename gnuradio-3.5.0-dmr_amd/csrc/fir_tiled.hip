@@ -30,6 +30,7 @@
 //    (8 B / output) and the fused quadrature demodulator.  The demodulator's
 //    predecessor of a tile's first output is recomputed by the whole workgroup
 //    (tree-order sum) instead of being exchanged between workgroups.
+#include <cstdio>
 #include <cstdlib>
 
 #include "device_math.h"
@@ -40,21 +41,30 @@ namespace grhip {
 
 // R = outputs per lane.  R = 8: one LDS read per 8 packed FMAs, 2 workgroups (8 waves)
 // per CU.  R = 4: twice the LDS reads per FMA but 3 workgroups (12 waves) per CU.
+#ifndef GRHIP_EXP
+#define GRHIP_EXP 0        // timing experiments only (wrong results): 1 no tap loads, 2 no window loads in the MAC loop,
+                           // 4 prefetch in one burst before the MAC loop, 8 no MAC loop
+#endif
 #ifndef GRHIP_TILED_R
 #define GRHIP_TILED_R 8
 #endif
 constexpr int TILED_R = GRHIP_TILED_R;
 constexpr int TILED_LOGR = TILED_R == 8 ? 3 : 2;
 static_assert(TILED_R == 8 || TILED_R == 4, "R must be 4 or 8");
-constexpr int TILED_THREADS = 256;
+#ifndef GRHIP_TILED_THREADS
+#define GRHIP_TILED_THREADS 256
+#endif
+constexpr int TILED_THREADS = GRHIP_TILED_THREADS;
+constexpr int TILED_WPW = 64 * TILED_R;           // outputs per wave
 constexpr int TILED_NT = TILED_THREADS * TILED_R;
-constexpr int TILED_WG_PER_CU = TILED_R == 8 ? 2 : 3;
+constexpr int TILED_WG_PER_CU = (TILED_R == 8 ? 2 : 3) * 256 / TILED_THREADS;
 constexpr int TILED_NI = TILED_R == 8 ? 18 : 11;       // 16-byte loads per lane per tile (upper bound)
 constexpr int TILED_LDS_LIMIT = (160 * 1024) / TILED_WG_PER_CU - 256;
 
 int tiled_R() { return TILED_R; }
 int tiled_NT() { return TILED_NT; }
 int tiled_wtab_len() { return 2 * TILED_THREADS + 1; }
+int tiled_load_span() { return 2 * TILED_THREADS; }
 int tiled_stab_len() { return TILED_NI; }
 
 __host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
@@ -67,14 +77,25 @@ typedef const float __attribute__((address_space(4))) *cfloat_p;
 // output).  slot(mm) = mm + mm/R.
 __host__ __device__ inline int tiled_phase_stride(int Tq)
 {
-    int MM = TILED_NT + Tq + 2 * TILED_R;
+    int MM = TILED_NT + Tq + 2 * TILED_R;   // largest mm touched: NT + Tq + 2R - 1 (MAC loop look-ahead reads)
     return MM + (MM >> TILED_LOGR) + 1;
 }
 __host__ inline size_t tiled_lds_bytes(int D, int Tq)
 {
-    return (size_t)D * tiled_phase_stride(Tq) * sizeof(float2) + (TILED_THREADS + 8) * sizeof(float2) +
-           260 * sizeof(float);      // exchange area + arctangent table
+    return (size_t)D * tiled_phase_stride(Tq) * sizeof(float2);
 }
+
+// The arctangent table of the fused demodulator (257 floats) lives in the pad slots of
+// polyphase component 0 (slot 9k+8 for R = 8, never touched by staging or the MAC loop):
+// two entries per pad slot, no LDS of its own.
+struct PadTable {
+    float *xsf;
+    __device__ __forceinline__ float &operator[](int i) const
+    {
+        return xsf[((((i >> 1) << TILED_LOGR) + (i >> 1) + TILED_R) << 1) + (i & 1)];
+    }
+};
+static_assert(((TILED_NT + 2 * TILED_R) >> TILED_LOGR) * 2 >= 257, "pad slots must hold the arctangent table");
 
 bool tiled_supported(int decim, int Tq)
 {
@@ -129,13 +150,16 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     constexpr int R = TILED_R, LOGR = TILED_LOGR, NT = TILED_NT, NI = TILED_NI;
     constexpr int LOGD = ilog2(D);
     constexpr int TW = CTAPS ? 2 : 1;               // floats per tap
+    constexpr bool ROT = EPI == EPI_ROTATE || EPI == EPI_ROTATE_DEMOD;     // rotator table multiply
+    constexpr bool DEMOD = EPI == EPI_ROTATE_DEMOD || EPI == EPI_DEMOD;    // fused quadrature demodulator
+    constexpr bool DIRECT = EPI == EPI_DEMOD;                              // ... on the pre-mixed accumulators
+    static_assert(!DIRECT || PREMIX, "EPI_DEMOD is the pre-mix form's epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *xs = (float2 *)smem;
 
     const int t = threadIdx.x;
     const int Tq = a.Tq;
     const int PS = tiled_phase_stride(Tq);
-    float2 *red = xs + (size_t)D * PS;              // [TILED_THREADS + 8] exchange area
     const int Lu = (NT + Tq) * D;                   // samples per tile, u = 0 <-> (n0-1)*D
     // tiles are numbered (stream, tile-in-stream); the pair is advanced incrementally
     // (a 64-bit division per tile costs ~150 scalar instructions)
@@ -154,7 +178,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
 
     // per-lane output phase corrections of the pre-mix form (tile independent)
     float2 vreg[R];
-    if (PREMIX) {
+    if (PREMIX && !DIRECT) {
         const float4 *vv = reinterpret_cast<const float4 *>(a.vtab + t * R);   // 64-byte aligned
 #pragma unroll
         for (int r = 0; r < R; r += 2) {
@@ -164,8 +188,8 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         }
     }
     // arctangent table of the fused demodulator lives in LDS (1 KB)
-    float *s_atan = reinterpret_cast<float *>(red + TILED_THREADS + 8);
-    if (EPI == EPI_ROTATE_DEMOD) {
+    const PadTable s_atan{reinterpret_cast<float *>(xs)};
+    if (DEMOD) {
         for (int i = t; i < 257; i += TILED_THREADS) s_atan[i] = a.atan_tab[i];
     }
 
@@ -175,7 +199,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     const bool pb_in_regs = Tq * D <= 64 * PB;
     float hb[PB * TW];
     float2 vb = make_float2(1.f, 0.f);
-    if (EPI == EPI_ROTATE_DEMOD) {
+    if (DEMOD) {
 #pragma unroll
         for (int c = 0; c < PB; ++c) {
             const int k = (t & 63) + 64 * c;
@@ -184,8 +208,8 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
 #pragma unroll
             for (int w2 = 0; w2 < TW; ++w2) hb[c * TW + w2] = a.hp[idx * TW + w2];
         }
-        const int jb = (NT / 4) * (t >> 6);             // tile-local index + 1 of the predecessor
-        if (PREMIX) vb = a.vtab[jb == 0 ? NT : jb - 1];
+        const int jb = TILED_WPW * (t >> 6);           // tile-local index + 1 of the predecessor
+        if (PREMIX && !DIRECT) vb = a.vtab[jb == 0 ? NT : jb - 1];
     }
 
     float4 pf[NI];
@@ -222,7 +246,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     // ---- rotator phases of a tile's outputs (issued at the end of the previous tile:
     //      a full stage + MAC phase ahead of their use, single register set) ----------
     auto fetch_phases = [&](int b) {
-        if (EPI >= EPI_ROTATE) {
+        if (ROT) {
             // uniform base + 32-bit lane offsets; indices clamped to the last valid output
             const float2 *gt = a.gtab + (long long)b * NT;
             const long long left = a.n_out - (long long)b * NT;
@@ -233,18 +257,21 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
                 gq[r] = gt[j < lim ? j : lim];
             }
             if (EPI == EPI_ROTATE_DEMOD) {
-                const int jb = (NT / 4) * (t >> 6) - 1;
+                const int jb = TILED_WPW * (t >> 6) - 1;
                 gb = (b == 0 && jb < 0) ? make_float2(1.f, 0.f) : gt[jb];
             }
         }
     };
 
     // ---- issue the HBM loads of one tile into registers ------------------------------
-    auto fetch = [&](int s, int b) {
-        __amdgpu_buffer_rsrc_t rsrc; int voff, off;
-        tile_geom(s, b, rsrc, voff, off);
+    // part < 0: all NI loads; otherwise the part-th of D equal shares (the shares are
+    // issued at the top of the D polyphase passes of the MAC loop: a burst of NI
+    // 1 KB loads per wave overruns the CU's memory queue and the wave sits at issue)
+    auto fetch = [&](__amdgpu_buffer_rsrc_t rsrc, int voff, int part) {
+        constexpr int PER = (NI + D - 1) / D;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
+            if (part >= 0 && i / PER != part) continue;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + i * (LANE_BYTES * TILED_THREADS), 0, 0);
             const f32x4 f = __builtin_bit_cast(f32x4, v);
             pf[i] = make_float4(f[0], f[1], f[2], f[3]);
@@ -296,7 +323,20 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         if (s >= a.n_streams) { s -= a.n_streams; ++b; }
     };
     int s = (int)(blockIdx.x % (unsigned)a.n_streams), bidx = (int)(blockIdx.x / (unsigned)a.n_streams);
-    if (bidx < tiles_per_stream) { fetch_phases(bidx); fetch(s, bidx); }
+    // The workgroups that share a CU start together and would stay in lockstep (both in
+    // the MAC loop, then both in the latency-bound phases).  Half of them start late by
+    // about half a tile so that one's MAC loop runs under the other's staging/epilogue.
+    if (a.skew_sleeps > 0) {
+        const bool late = a.skew_mode == 1 ? blockIdx.x >= gridDim.x / 2 : (blockIdx.x & 1);
+        if (late)
+            for (int i = 0; i < a.skew_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    if (bidx < tiles_per_stream) {
+        __amdgpu_buffer_rsrc_t rsrc; int voff, off;
+        tile_geom(s, bidx, rsrc, voff, off);
+        fetch_phases(bidx);
+        fetch(rsrc, voff, -1);
+    }
     STAMP_DECL;
 
     while (bidx < tiles_per_stream) {
@@ -312,7 +352,12 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         // next tile's HBM traffic flies under this tile's MAC loop.  (Issuing it in one
         // burst per polyphase component instead was measured slower: unrolling the phase
         // loop costs more registers than the 256-VGPR budget has.)
-        if (b_nxt < tiles_per_stream) fetch(s_nxt, b_nxt);
+        __amdgpu_buffer_rsrc_t rsrc_n; int voff_n, off_n;
+        tile_geom(s_nxt, b_nxt, rsrc_n, voff_n, off_n);
+        if (b_nxt >= tiles_per_stream) voff_n = 0x7ffff000 - NI * LANE_BYTES * TILED_THREADS;   // out of range: zeros, no traffic
+#if GRHIP_EXP & 4
+        fetch(rsrc_n, voff_n, -1);
+#endif
         STAMP(2);
 
         // ---------------- predecessor of each WAVE's first output (fused demod) -----
@@ -321,13 +366,17 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         // phase factors are lane constants / were fetched a tile ahead, so nothing here
         // queues behind the prefetch that was just issued.
         float2 yb = make_float2(0.f, 0.f);
-        if (EPI == EPI_ROTATE_DEMOD) {
+        if (DEMOD) {
             const int wv = t >> 6, ln = t & 63;
             if (bidx == 0 && wv == 0) {
                 yb = a.y_prev ? a.y_prev[s] : make_float2(0.f, 0.f);
+                if (DIRECT) {           // carried in the acc * v frame; v[-1] = vtab[NT]
+                    const float2 vm = a.vtab[NT];
+                    yb = cmul_fma(yb, make_float2(vm.x, -vm.y));
+                }
             } else {
                 float2 part = make_float2(0.f, 0.f);
-                const int mb = (NT / 4) * wv + R - 1;          // mm of the output's first sample
+                const int mb = TILED_WPW * wv + R - 1;         // mm of the output's first sample
                 if (pb_in_regs) {
 #pragma unroll
                     for (int c = 0; c < PB; ++c) {
@@ -366,71 +415,121 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
                     }
                 }
                 yb = make_float2(wave_sum(part.x), wave_sum(part.y));
-                if (PREMIX) yb = cmul_fma(yb, vb);
-                yb = cmul_ref(yb, gb);
+                if (PREMIX && !DIRECT) yb = cmul_fma(yb, vb);
+                if (ROT) yb = cmul_ref(yb, gb);
             }
         }
 
         STAMP(3);
         // ---------------- MAC loop: R outputs per lane -----------------------------
-        float2 acc[R];
+        // The lane's samples of a pass (polyphase component p) come in blocks of R
+        // (block b = samples bR .. bR+R-1, LDS slot offset b(R+1)).  Step k of the pass
+        // multiplies taps kR .. kR+R-1 against blocks k and k+1.  Everything a step needs
+        // is requested one step (R*R packed FMAs, ~256 cycles) ahead: block k+2 at the top
+        // of step k and the taps of step k+1 inside it.  Three register sets take the
+        // block roles in turn, so nothing is moved.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef float tapvec __attribute__((ext_vector_type(R * TW)));
+        static_assert(R == 8, "the MAC step below is written for 8 accumulators");
+        f32x2 av[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
-
+        for (int r = 0; r < R; ++r) av[r] = f32x2{0.f, 0.f};
         const int lane_base = (t + 1) * R + (t + 1);       // slot of mm = (t+1)R
-        const int nph = (a.ablate & 2) ? 0 : D;
-        for (int p = 0; p < nph; ++p) {
-            const float2 *xp = xs + p * PS + lane_base;
-            const cfloat_p tp = hp + (size_t)p * Tq * TW;
-            float2 w[R];
+        const int nb = Tq >> LOGR;                         // steps per pass
+        tapvec hcur = *reinterpret_cast<const tapvec __attribute__((address_space(4))) *>(hp);
+
+        // Real taps: one step is ONE asm statement -- the scalar load of the next step's
+        // taps, the 64 packed FMAs (tap = one half of an SGPR pair, chosen with op_sel) and
+        // the wait for that load.  The load is in flight only inside the statement, so the
+        // compiler never sees registers with pending writes.  (Left to the compiler, the
+        // tap load is moved next to its use and every step waits a scalar-cache latency;
+        // that wait also drains the LDS reads just issued, because SMEM and LDS share a
+        // counter.)  The tap table is phase-major, contiguous and padded by R taps, so the
+        // load of the last step of a pass fetches the first step of the next pass.
+        auto step_real = [&](const f32x2 (&cur)[R], const f32x2 (&nxt)[R], int g) {
+            const f32x2 h01{hcur[0], hcur[1]}, h23{hcur[2], hcur[3]}, h45{hcur[4], hcur[5]}, h67{hcur[6], hcur[7]};
+            const cfloat_p src = hp + (size_t)(g + 1) * R;
+            tapvec hnext;
+            asm volatile(
+#include "mac_step.inc"
+                : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]),
+                  "+v"(av[7]), "=&s"(hnext)
+                : "v"(cur[0]), "v"(cur[1]), "v"(cur[2]), "v"(cur[3]), "v"(cur[4]), "v"(cur[5]), "v"(cur[6]),
+                  "v"(cur[7]), "v"(nxt[0]), "v"(nxt[1]), "v"(nxt[2]), "v"(nxt[3]), "v"(nxt[4]), "v"(nxt[5]),
+                  "v"(nxt[6]), "s"(h01), "s"(h23), "s"(h45), "s"(h67), "s"(src));
+            hcur = hnext;
+        };
+        // Complex taps: plain C++, the compiler schedules the tap loads.
+        auto step_cplx = [&](const f32x2 (&cur)[R], const f32x2 (&nxt)[R], int g) {
+            const tapvec h = hcur;
 #pragma unroll
-            for (int j = 0; j < R; ++j) w[j] = xp[j];
-            float hn[R * TW];
+            for (int i = 0; i < R * TW; ++i) hcur[i] = hp[(size_t)(g + 1) * (R * TW) + i];
 #pragma unroll
-            for (int k = 0; k < R * TW; ++k) hn[k] = tp[k];
-            for (int q0 = 0; q0 < Tq; q0 += R) {
-                float h[R * TW];
+            for (int qq = 0; qq < R; ++qq) {
 #pragma unroll
-                for (int k = 0; k < R * TW; ++k) h[k] = hn[k];
-                // request the taps of the next 8 steps now (the table is padded by R
-                // taps, so the read past the last step of the last phase stays in bounds)
-#pragma unroll
-                for (int k = 0; k < R * TW; ++k) hn[k] = tp[(q0 + R) * TW + k];
-                const int nxt = q0 + R + (q0 >> LOGR) + 1;   // slot offset of sample j = q0+R (+qq)
-#pragma unroll
-                for (int qq = 0; qq < R; ++qq) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float2 xv = w[(qq + r) & (R - 1)];
-                        if (CTAPS) {
-                            const float hr = h[2 * qq], hi = h[2 * qq + 1];
-                            acc[r].x = __builtin_fmaf(hr, xv.x, acc[r].x);
-                            acc[r].x = __builtin_fmaf(-hi, xv.y, acc[r].x);
-                            acc[r].y = __builtin_fmaf(hr, xv.y, acc[r].y);
-                            acc[r].y = __builtin_fmaf(hi, xv.x, acc[r].y);
-                        } else {
-                            acc[r].x = __builtin_fmaf(h[qq], xv.x, acc[r].x);
-                            acc[r].y = __builtin_fmaf(h[qq], xv.y, acc[r].y);
-                        }
-                    }
-                    w[qq] = xp[nxt + qq];
+                for (int r = 0; r < R; ++r) {
+                    const int idx = qq + r;
+                    const f32x2 xv = idx < R ? cur[idx] : nxt[idx - R];
+                    const float hr = h[(2 * qq) % (R * TW)], hi = h[(2 * qq + 1) % (R * TW)];
+                    av[r].x = __builtin_fmaf(hr, xv.x, av[r].x);
+                    av[r].x = __builtin_fmaf(-hi, xv.y, av[r].x);
+                    av[r].y = __builtin_fmaf(hr, xv.y, av[r].y);
+                    av[r].y = __builtin_fmaf(hi, xv.x, av[r].y);
                 }
             }
+        };
+
+#if GRHIP_EXP & 8
+        fetch(rsrc_n, voff_n, -1);
+#else
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+#if !(GRHIP_EXP & 4)
+            fetch(rsrc_n, voff_n, p);       // p is a compile-time constant: the pass loop is unrolled
+#endif
+            const f32x2 *xp = reinterpret_cast<const f32x2 *>(xs) + p * PS + lane_base;
+            f32x2 wA[R], wB[R], wC[R];
+            auto load_blk = [&](f32x2 (&dst)[R], int blk) {
+#if !(GRHIP_EXP & 2)
+#pragma unroll
+                for (int j = 0; j < R; ++j) dst[j] = xp[blk * (R + 1) + j];
+#endif
+            };
+            auto step = [&](const f32x2 (&cur)[R], const f32x2 (&nxt)[R], f32x2 (&ld)[R], int k) {
+                load_blk(ld, k + 2);
+                if (CTAPS) step_cplx(cur, nxt, p * nb + k);
+                else step_real(cur, nxt, p * nb + k);
+            };
+            load_blk(wA, 0);
+            load_blk(wB, 1);
+            int k = 0;
+            for (; k + 3 <= nb; k += 3) {
+                step(wA, wB, wC, k);
+                step(wB, wC, wA, k + 1);
+                step(wC, wA, wB, k + 2);
+            }
+            if (k < nb) step(wA, wB, wC, k);
+            if (k + 1 < nb) step(wB, wC, wA, k + 1);
         }
+#endif
+
+        float2 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = make_float2(av[r].x, av[r].y);
 
         STAMP(4);
         // ---------------- epilogue ---------------------------------------------------
         const long long nl = n0 + (long long)t * R;          // first output of this lane
-        if (PREMIX) {
+        if (PREMIX && !DIRECT) {
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = cmul_fma(acc[r], vreg[r]);
         }
-        if (EPI >= EPI_ROTATE) {
+        if (ROT) {
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = cmul_ref(acc[r], gq[r]);   // gr_rotator: z = in * d_phase
         }
 
-        if (EPI != EPI_ROTATE_DEMOD) {
+        if (!DEMOD) {
             float2 *__restrict__ y = a.y_out + s * a.y_stride;
             if (a.vec_store && nl + R <= a.n_out) {
                 float4 *dst = reinterpret_cast<float4 *>(y + nl);
@@ -470,12 +569,12 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
             if (a.y_last && last >= nl && last < nl + R) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    if (nl + r == last) a.y_last[s] = acc[r];
+                    if (nl + r == last) a.y_last[s] = DIRECT ? cmul_fma(acc[r], a.vtab[t * R + r]) : acc[r];
             }
         }
         if (b_nxt < tiles_per_stream) fetch_phases(b_nxt);      // for the next tile's epilogue
         STAMP(5);
-        __syncthreads();        // xs / red are rewritten by the next tile
+        __syncthreads();        // xs is rewritten by the next tile
         STAMP(6);
         s = s_nxt; bidx = b_nxt;
     }
@@ -521,13 +620,15 @@ static int launch_tiled_d(bool ctaps, bool premix, int epi, const FirTiledArgs &
         switch (epi) {
         case EPI_NONE: return launch_tiled_inst<D, true, false, EPI_NONE>(a, st);
         case EPI_ROTATE: return launch_tiled_inst<D, true, false, EPI_ROTATE>(a, st);
-        default: return launch_tiled_inst<D, true, false, EPI_ROTATE_DEMOD>(a, st);
+        case EPI_ROTATE_DEMOD: return launch_tiled_inst<D, true, false, EPI_ROTATE_DEMOD>(a, st);
+        default: return fail(GRHIP_EINVAL, "complex taps have no direct demodulator epilogue");
         }
     }
     if (premix) {
         switch (epi) {
         case EPI_ROTATE: return launch_tiled_inst<D, false, true, EPI_ROTATE>(a, st);
         case EPI_ROTATE_DEMOD: return launch_tiled_inst<D, false, true, EPI_ROTATE_DEMOD>(a, st);
+        case EPI_DEMOD: return launch_tiled_inst<D, false, true, EPI_DEMOD>(a, st);
         default: return fail(GRHIP_EINVAL, "premix needs a rotate epilogue");
         }
     }
@@ -560,6 +661,13 @@ int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiled
     static int ablate = -1;
     if (ablate < 0) { const char *e = getenv("GRHIP_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
+    static int skew_mode = -1, skew_sleeps = 0;
+    if (skew_mode < 0) {
+        const char *e = getenv("GRHIP_SKEW");        // "mode,sleeps" (tuning knob)
+        skew_mode = 0;
+        if (e) sscanf(e, "%d,%d", &skew_mode, &skew_sleeps);
+    }
+    a.skew_mode = skew_mode; a.skew_sleeps = skew_sleeps;
     switch (decim) {
     case 1: return launch_tiled_d<1>(ctaps, premix, epi, a, st);
     case 2: return launch_tiled_d<2>(ctaps, premix, epi, a, st);

@@ -10,6 +10,7 @@
 // every capture that starts from a fresh block (reset()).
 #pragma once
 #include <complex>
+#include <cstdlib>
 #include <vector>
 
 #include "grhip_internal.h"
@@ -65,6 +66,13 @@ struct XlatingCore {
     }
     void reset();
     int ensure_rot(long long n, const float2 **gtab);
+    int phase_before_pos(std::complex<float> *g);
+    // fused demodulator on the pre-mixed accumulators (EPI_DEMOD): FAST mode, real prototype taps
+    bool demod_is_direct(int mode, bool demod) const
+    {
+        static const bool off = getenv("GRHIP_NO_DIRECT") != nullptr;     // A/B knob (profiling only)
+        return !off && demod && mode == GRHIP_MODE_FAST && use_tiled && premix;
+    }
     // d_in item 0 = input[0] of output 0 (oldest history item); items with index
     // < n_lo or >= n_in read as zero.  n_streams > 1: stream s at d_in + s*x_stride,
     // outputs at d_y/d_demod + s*out_stride, y_prev[s] / y_last[s].

@@ -249,6 +249,26 @@ def test_fused_xlating_demod_cfg2(gpu, po, wl):
     assert ok, worst
 
 
+def test_fused_xlating_demod_mode_switch_mid_stream(gpu, po, wl):
+    """FAST and GENERIC keep the demodulator's one-sample carry in different frames
+    (fir_kernels.h, EPI_DEMOD); switching between work() calls converts it"""
+    c = wl.CFG2
+    n = 120_000
+    x = wl.fsk4_capture(n, stream_id=9)
+    proto = wl.cfg2_proto_taps()
+    ref = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], x)
+    blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
+    xin = wl.with_history(x, 255)
+    out, pos = [], 0
+    for k, nchunk in enumerate((10_000, 5_000, 7_500, 7_500)):
+        blk.set_mode(gpu.MODE_FAST if k % 2 == 0 else gpu.MODE_GENERIC)
+        out.append(blk.work(nchunk, xin[pos * 4: (pos + nchunk) * 4 + 255]))
+        pos += nchunk
+    got = np.concatenate(out)
+    ok, worst = demod_close(got, ref[:pos])
+    assert ok, worst
+
+
 def test_unfused_pipeline_equals_fused(gpu, po, wl):
     """tb.connect(xlating, demod) as two blocks vs the fused hier block"""
     c = wl.CFG2
