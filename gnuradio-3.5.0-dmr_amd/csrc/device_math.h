@@ -21,63 +21,66 @@ __device__ __forceinline__ float2 cmul_fma(float2 a, float2 b)
     return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
 }
 
-// gr_fast_atan2f (gnuradio-core/src/lib/general/gr_fast_atan2f.cc:125-198).
-// REAL = float but the literals are double: the comparisons and the "- .5"
-// are evaluated in double and narrowed on assignment, as written there.
-// `tab` is anything indexable with 0..256: a pointer, or a view of a table stored with gaps
-template <class Tab>
+// the same product as cmul_fma in two packed instructions: the halves of the operands
+// are routed with op_sel and the one negation is an operand modifier, so nothing is
+// moved or sign-flipped beforehand
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t cmul_pk(f32x2_t a, f32x2_t b)
+{
+    f32x2_t t, r;
+    // t = (-(a.y * b.y), a.y * b.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    // r = (fma(a.x, b.x, t.x), fma(a.x, b.y, t.y))
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+
+// gr_fast_atan2f (gnuradio-core/src/lib/general/gr_fast_atan2f.cc:125-198), written
+// without branches (on a GPU every lane of a wave sits in a different octant, so each
+// branch of the original would be executed by every wave anyway).  With EXACT_DIV the
+// result is bit-identical to the reference for every input:
+//  * :140  z = min(|y|,|x|) / max(|y|,|x|): the same IEEE division whichever branch the
+//    reference takes;
+//  * :147  `z < TAN_MAP_RES` compares in double against 0.003921569; for a binary32 z that
+//    is exactly `z < 0x1.010104p-8f` (0x3b808082, the smallest float >= the constant);
+//  * :151  `z * (REAL)256 - .5`: the product is exact (power of two) and the double
+//    subtraction is exact before narrowing, i.e. one float subtraction;
+//  * :161-195  the eight octant cases are q + s*base, negated for y < 0, with
+//    q in {0, pi, pi/2}: a - b == -(b - a) and 0 + b == b hold bit for bit in IEEE
+//    arithmetic, so the selects reproduce the reference's additions and subtractions.
+// EXACT_DIV = false (FAST-mode fused epilogue only) replaces the division by
+// ldexp(num, -e) * rcp(mantissa(den)): 1 ulp, any magnitude, six instructions fewer.
+// `tab` is anything indexable with 0..256: a pointer, or a view of a table stored with gaps.
+template <bool EXACT_DIV = true, class Tab>
 __device__ __forceinline__ float fast_atan2f(float y, float x, Tab tab)
 {
-    float x_abs, y_abs, z;
-    float alpha, angle, base_angle;
-    int index;
-
-    if ((y == 0.0f) && (x == 0.0f)) return 0.0f;          // :133
-
-    y_abs = __builtin_fabsf(y);
-    x_abs = __builtin_fabsf(x);
-    if (y_abs < x_abs) z = y_abs / x_abs;                  // :140 (IEEE divide)
-    else               z = x_abs / y_abs;
-
-    // :147 `z < TAN_MAP_RES` compares in double against 0.003921569.  For a binary32 z
-    // that is exactly `z < 0x1.010104p-8f` (0x3b808082, the smallest float >= the
-    // constant), so no double arithmetic is needed.
-    // :151 `z * (REAL)256 - .5`: the product is exact (power of two) and the double
-    // subtraction is exact before narrowing, i.e. one float subtraction.
-    if (z < __builtin_bit_cast(float, 0x3b808082u)) {
-        base_angle = z;
+    const float y_abs = __builtin_fabsf(y), x_abs = __builtin_fabsf(x);
+    const bool big = x_abs > y_abs;                        // :161 (and :140 `y_abs < x_abs`)
+    const float num = big ? y_abs : x_abs, den = big ? x_abs : y_abs;
+    float z;
+    if (EXACT_DIV) {
+        z = num / den;                                     // :140-143 (IEEE divide)
     } else {
-        alpha = z * 256.0f - 0.5f;
-        index = (int)alpha;
-        index = index < 0 ? 0 : (index > 255 ? 255 : index);   // no-op for finite input; keeps NaN in bounds
-        alpha -= (float)index;
-        float t0 = tab[index], t1 = tab[index + 1];
-        base_angle = t0;
-        base_angle += (t1 - t0) * alpha;                   // :156-157, unfused
+        const int e = __builtin_amdgcn_frexp_expf(den);
+        z = __builtin_amdgcn_ldexpf(num, -e) * __builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(den));
     }
+    float alpha = z * 256.0f - 0.5f;                       // :151
+    int index = (int)alpha;
+    index = index < 0 ? 0 : (index > 255 ? 255 : index);   // no-op for finite z >= TAN_MAP_RES; keeps the rest in bounds
+    alpha -= (float)index;
+    const float t0 = tab[index], t1 = tab[index + 1];
+    float interp = t0;
+    interp += (t1 - t0) * alpha;                           // :156-157, unfused
+    const float base_angle = z < __builtin_bit_cast(float, 0x3b808082u) ? z : interp;   // :147
 
     const float PI_F = (float)3.14159265358979323846;
     const float HALF_PI_F = (float)1.57079632679489661923;
-    if (x_abs > y_abs) {                                   // :161
-        if (x >= 0.0f) {
-            angle = (y >= 0.0f) ? base_angle : -base_angle;
-        } else {
-            angle = PI_F;
-            if (y >= 0.0f) angle -= base_angle;
-            else           angle = base_angle - angle;
-        }
-    } else {
-        if (y >= 0.0f) {
-            angle = HALF_PI_F;
-            if (x >= 0.0f) angle -= base_angle;
-            else           angle += base_angle;
-        } else {
-            angle = -HALF_PI_F;
-            if (x >= 0.0f) angle += base_angle;
-            else           angle -= base_angle;
-        }
-    }
-    return angle;
+    const bool xpos = x >= 0.0f, ypos = y >= 0.0f;
+    const float q = big ? (xpos ? 0.0f : PI_F) : HALF_PI_F;
+    const float sb = (big != xpos) ? -base_angle : base_angle;
+    const float ap = q + sb;
+    float angle = ypos ? ap : -ap;
+    return ((y == 0.0f) && (x == 0.0f)) ? 0.0f : angle;    // :133
 }
 
 // one output of gr_quadrature_demod_cf::work (general/gr_quadrature_demod_cf.cc:57-59)
@@ -85,7 +88,15 @@ template <class Tab>
 __device__ __forceinline__ float quad_demod_one(float2 cur, float2 prev, float gain, Tab tab)
 {
     float2 product = cmul_ref(cur, make_float2(prev.x, -prev.y));   // in[i] * conj(in[i-1])
-    return gain * fast_atan2f(product.y, product.x, tab);
+    return gain * fast_atan2f<true>(product.y, product.x, tab);
+}
+
+// FAST-mode fused epilogue: fused product, 1-ulp division
+template <class Tab>
+__device__ __forceinline__ float quad_demod_fast(float2 cur, float2 prev, float gain, Tab tab)
+{
+    const float2 product = cmul_fma(cur, make_float2(prev.x, -prev.y));
+    return gain * fast_atan2f<false>(product.y, product.x, tab);
 }
 
 // gr_branchless_clip (general/gr_math.h:63-69)

@@ -95,7 +95,14 @@ struct PadTable {
         return xsf[((((i >> 1) << TILED_LOGR) + (i >> 1) + TILED_R) << 1) + (i & 1)];
     }
 };
-static_assert(((TILED_NT + 2 * TILED_R) >> TILED_LOGR) * 2 >= 257, "pad slots must hold the arctangent table");
+struct PadSlots {       // 8-byte entries in the pad slots from number 136 on
+    float __attribute__((ext_vector_type(2))) *xs2;
+    __device__ __forceinline__ float __attribute__((ext_vector_type(2))) &operator[](int i) const
+    {
+        return xs2[((136 + i) << TILED_LOGR) + (136 + i) + TILED_R];
+    }
+};
+static_assert(((TILED_NT + 2 * TILED_R) >> TILED_LOGR) >= 136 + TILED_NI, "pad slots must hold the arctangent and step tables");
 
 bool tiled_supported(int decim, int Tq)
 {
@@ -165,15 +172,16 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     // (a 64-bit division per tile costs ~150 scalar instructions)
     const int tiles_per_stream = (int)((a.n_out + NT - 1) / NT);
     const cfloat_p hp = (cfloat_p)a.hp;             // phase-major taps, padded by R entries
-    const cfloat_p stab = (cfloat_p)a.stab;
 
     // lane constants of the pre-mix phasor: W[v] = e^{jw(v-D)}, v = 2t-1, 2t, 2t+1
     // (table entry v+1 holds W[v], v = -1 .. 511)
-    float2 wA = make_float2(1.f, 0.f), wB = wA, wC = wA;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 wA{1.f, 0.f}, wB = wA, wC = wA;
     if (PREMIX) {
-        wA = a.wtab[2 * t];
-        wB = a.wtab[2 * t + 1];
-        wC = a.wtab[2 * t + 2];
+        const f32x2 *wt = reinterpret_cast<const f32x2 *>(a.wtab);
+        wA = wt[2 * t];
+        wB = wt[2 * t + 1];
+        wC = wt[2 * t + 2];
     }
 
     // per-lane output phase corrections of the pre-mix form (tile independent)
@@ -189,6 +197,12 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     }
     // arctangent table of the fused demodulator lives in LDS (1 KB)
     const PadTable s_atan{reinterpret_cast<float *>(xs)};
+    // ... and the staging phasor steps e^{jw 512 i} in the pad slots after it (one per slot)
+    const PadSlots s_step{reinterpret_cast<f32x2 *>(xs)};
+    if (PREMIX) {
+        if (t < NI) s_step[t] = reinterpret_cast<const f32x2 *>(a.stab)[t];
+        __syncthreads();        // read by every wave in the first staging pass
+    }
     if (DEMOD) {
         for (int i = t; i < 257; i += TILED_THREADS) s_atan[i] = a.atan_tab[i];
     }
@@ -284,31 +298,33 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     auto stage = [&](int s, int b) {
         __amdgpu_buffer_rsrc_t rsrc; int voff, off;
         tile_geom(s, b, rsrc, voff, off);
-        const float2 w0l = off ? wA : wB, w1l = off ? wB : wC;
+        const f32x2 w0l = off ? wA : wB, w1l = off ? wB : wC;
         const int ub = -off + 2 * t;
         constexpr int SLOT_STEP = (2 * TILED_THREADS / D) + (2 * TILED_THREADS / D) / R;
+        constexpr int FULL = NT * D / (2 * TILED_THREADS);     // rounds that lie inside the tile for every lane
         const int mm0 = (ub >> LOGD) - 1 + R, p0 = ub & (D - 1);
         const int mm1 = ((ub + 1) >> LOGD) - 1 + R, p1 = (ub + 1) & (D - 1);
-        float2 *dst0 = xs + p0 * PS + mm0 + (mm0 >> LOGR);
-        float2 *dst1 = xs + p1 * PS + mm1 + (mm1 >> LOGR);
-        float sv[2 * NI];
-        if (PREMIX) {
-#pragma unroll
-            for (int k = 0; k < 2 * NI; ++k) sv[k] = stab[k];       // wave-uniform e^{jw 512 i}
-        }
+        f32x2 *dst0 = reinterpret_cast<f32x2 *>(xs) + p0 * PS + mm0 + (mm0 >> LOGR);
+        f32x2 *dst1 = reinterpret_cast<f32x2 *>(xs) + p1 * PS + mm1 + (mm1 >> LOGR);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int u = ub + 2 * TILED_THREADS * i;
-            if (u < Lu) {
-                float2 e0 = make_float2(pf[i].x, pf[i].y), e1 = make_float2(pf[i].z, pf[i].w);
-                if (FP == 1) { e0 = make_float2(pf[i].x, pf[i].y); e1 = make_float2(pf[i].y, pf[i].z); }   // (x[u],x[u+1]), (x[u+1],x[u+2])
-                if (FP == 2) { e0 = make_float2(pf[i].x, pf[i].z); e1 = make_float2(pf[i].y, pf[i].w); }   // (x[u],x[u+2]), (x[u+1],x[u+3])
-                if (PREMIX) {
-                    const float2 si = make_float2(sv[2 * i], sv[2 * i + 1]);
-                    e0 = cmul_fma(e0, cmul_fma(w0l, si));
-                    e1 = cmul_fma(e1, cmul_fma(w1l, si));
-                }
-                if (u >= 0) dst0[SLOT_STEP * i] = e0;
+            f32x2 e0{pf[i].x, pf[i].y}, e1{pf[i].z, pf[i].w};
+            if (FP == 1) { e0 = f32x2{pf[i].x, pf[i].y}; e1 = f32x2{pf[i].y, pf[i].z}; }   // (x[u],x[u+1]), (x[u+1],x[u+2])
+            if (FP == 2) { e0 = f32x2{pf[i].x, pf[i].z}; e1 = f32x2{pf[i].y, pf[i].w}; }   // (x[u],x[u+2]), (x[u+1],x[u+3])
+            if (PREMIX) {
+                const f32x2 si = s_step[i];             // wave-uniform e^{jw 512 i}: LDS broadcast read
+                e0 = cmul_pk(e0, cmul_pk(w0l, si));
+                e1 = cmul_pk(e1, cmul_pk(w1l, si));
+            }
+            if (i == 0) {
+                if (u >= 0) dst0[0] = e0;
+                dst1[0] = e1;
+            } else if (i < FULL) {
+                dst0[SLOT_STEP * i] = e0;
+                dst1[SLOT_STEP * i] = e1;
+            } else {
+                if (u < Lu) dst0[SLOT_STEP * i] = e0;
                 if (u + 1 < Lu) dst1[SLOT_STEP * i] = e1;
             }
         }
@@ -428,7 +444,6 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         // is requested one step (R*R packed FMAs, ~256 cycles) ahead: block k+2 at the top
         // of step k and the taps of step k+1 inside it.  Three register sets take the
         // block roles in turn, so nothing is moved.
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef float tapvec __attribute__((ext_vector_type(R * TW)));
         static_assert(R == 8, "the MAC step below is written for 8 accumulators");
         f32x2 av[R];
@@ -551,7 +566,8 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
             float d[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                d[r] = (a.ablate & 4) ? acc[r].x + prev.y : quad_demod_one(acc[r], prev, a.gain, s_atan);
+                d[r] = (a.ablate & 4) ? acc[r].x + prev.y
+                       : DIRECT ? quad_demod_fast(acc[r], prev, a.gain, s_atan) : quad_demod_one(acc[r], prev, a.gain, s_atan);
                 prev = acc[r];
             }
             float *__restrict__ o = a.d_out + s * a.d_stride;
