@@ -41,7 +41,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--captures", type=int, default=16, help="captures per GPU per step")
+    ap.add_argument("--captures", type=int, default=64, help="captures per GPU per step")
+    ap.add_argument("--ramp-ms", type=float, default=400.0,
+                    help="untimed launches before the W warm-up steps until this much GPU time has passed: the "
+                         "shader clock of an idle MI355X takes tens of ms of load to reach its steady state "
+                         "(the same step measures 0.72 ms in the first 10 ms and 0.59 ms later)")
     ap.add_argument("--samples", type=int, default=10_000_000, help="complex samples per capture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-capture-launch", action="store_true",
@@ -192,6 +196,11 @@ def main():
         step.hist_buf[:, hist:hist + n, :] = buf[:, :n, :]
 
     torch.cuda.synchronize()
+    # clock ramp (untimed, not counted as steps), then the W warm-up steps
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < a.ramp_ms:
+        step()
+        stream.synchronize()
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -230,8 +239,8 @@ def main():
             "config": {"workload": "freq_xlating_fir_filter_ccc 256-tap decim=4 + quadrature_demod_cf, "
                                    "10 MS/s synthetic 4FSK IQ", "captures_per_gpu_per_step": B,
                        "samples_per_capture": n, "sharding": "independent captures per rank, "
-                       "RCCL broadcast of taps only"},
-            "roofline": {"bound": "hbm", "kernel": "fir_tiled_kernel<D=4,premix,rotate+demod>",
+                       "RCCL broadcast of taps only", "clock_ramp_ms_untimed": a.ramp_ms},
+            "roofline": {"bound": "hbm", "kernel": "fir_tiled_kernel<D=4,premix,demod>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, n, launches_per_step),
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,

@@ -183,7 +183,7 @@ int XlatingCore::phase_before_pos(std::complex<float> *g)
 void XlatingCore::release()
 {
     d_taps_generic.release(); d_hp.release(); d_wtab.release(); d_stab.release(); d_vtab.release(); d_rot.release();
-    scratch_y.release();
+    scratch_y.release(); sched.release();
 }
 
 // run the FIR + rotator (+ demod) for n_out outputs on device pointers.
@@ -211,6 +211,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         a.y_out = d_y; a.d_out = d_demod; a.gain = gain;
         a.y_stride = out_stride; a.d_stride = out_stride;
         a.y_prev = y_prev; a.y_last = y_last; a.atan_tab = atan_tab;
+        a.sched = sched.get();
         uintptr_t o = demod ? (uintptr_t)d_demod : (uintptr_t)d_y;
         a.vec_store = (o & 15) == 0 && ((out_stride * (demod ? 4 : 8)) & 15) == 0;
         rc = launch_fir_tiled(decim, !premix, premix, direct ? EPI_DEMOD : demod ? EPI_ROTATE_DEMOD : EPI_ROTATE, a,
@@ -253,6 +254,7 @@ struct grhip_fir_filter : HandleBase {
     bool updated = false;
     int ntaps = 0;
     DevBuf d_taps_rev, d_hp;
+    SchedBuf sched;
     int Tq = 0;
     bool use_tiled = false;
 
@@ -294,6 +296,7 @@ struct grhip_fir_filter : HandleBase {
             a.hp = d_hp.as<float>(); a.Tq = Tq; a.n_out = n;
             a.y_out = (float2 *)d_out;
             a.vec_store = (((uintptr_t)d_out) & 15) == 0;
+            a.sched = sched.get();
             if (kind != FIR_FFF) return launch_fir_tiled(dec, kind == FIR_CCC, false, EPI_NONE, a, 1, st);
             // gr_fir_fff: output pairs (y[2j], y[2j+1]); an odd last output goes through the generic kernel
             a.fpair = dec;
@@ -326,7 +329,7 @@ int grhip_fir_filter_create(grhip_fir_filter **h, const char *kind, int decimati
     f->kind = k; f->decim = decimation; f->mode = default_mode();
     int rc = f->init_device(device);
     if (!rc) rc = f->install(std::vector<float>(taps, taps + ntaps * f->tw()));
-    if (rc) { f->d_taps_rev.release(); f->d_hp.release(); f->destroy_base(); delete f; return rc; }
+    if (rc) { f->d_taps_rev.release(); f->d_hp.release(); f->sched.release(); f->destroy_base(); delete f; return rc; }
     *h = f;
     return GRHIP_OK;
 }
@@ -335,7 +338,7 @@ void grhip_fir_filter_destroy(grhip_fir_filter *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    h->d_taps_rev.release(); h->d_hp.release();
+    h->d_taps_rev.release(); h->d_hp.release(); h->sched.release();
     h->destroy_base();
     delete h;
 }

@@ -50,7 +50,14 @@ __device__ __forceinline__ f32x2_t cmul_pk(f32x2_t a, f32x2_t b)
 //    arithmetic, so the selects reproduce the reference's additions and subtractions.
 // EXACT_DIV = false (FAST-mode fused epilogue only) replaces the division by
 // ldexp(num, -e) * rcp(mantissa(den)): 1 ulp, any magnitude, six instructions fewer.
-// `tab` is anything indexable with 0..256: a pointer, or a view of a table stored with gaps.
+// `tab`: a pointer to the 257 floats, or a view that returns the pair (tab[i], tab[i+1]).
+__device__ __forceinline__ void atan_pair(const float *tab, int i, float &t0, float &t1) { t0 = tab[i]; t1 = tab[i + 1]; }
+template <class PairView>
+__device__ __forceinline__ void atan_pair(PairView tab, int i, float &t0, float &t1)
+{
+    const auto p = tab[i];
+    t0 = p.x; t1 = p.y;
+}
 template <bool EXACT_DIV = true, class Tab>
 __device__ __forceinline__ float fast_atan2f(float y, float x, Tab tab)
 {
@@ -68,7 +75,8 @@ __device__ __forceinline__ float fast_atan2f(float y, float x, Tab tab)
     int index = (int)alpha;
     index = index < 0 ? 0 : (index > 255 ? 255 : index);   // no-op for finite z >= TAN_MAP_RES; keeps the rest in bounds
     alpha -= (float)index;
-    const float t0 = tab[index], t1 = tab[index + 1];
+    float t0, t1;
+    atan_pair(tab, index, t0, t1);
     float interp = t0;
     interp += (t1 - t0) * alpha;                           // :156-157, unfused
     const float base_angle = z < __builtin_bit_cast(float, 0x3b808082u) ? z : interp;   // :147

@@ -43,7 +43,7 @@ namespace grhip {
 // per CU.  R = 4: twice the LDS reads per FMA but 3 workgroups (12 waves) per CU.
 #ifndef GRHIP_EXP
 #define GRHIP_EXP 0        // timing experiments only (wrong results): 1 no tap loads, 2 no window loads in the MAC loop,
-                           // 4 prefetch in one burst before the MAC loop, 8 no MAC loop
+                           // 4 prefetch in one burst before the MAC loop, 8 no MAC loop, 16 no demodulator arithmetic
 #endif
 #ifndef GRHIP_TILED_R
 #define GRHIP_TILED_R 8
@@ -82,27 +82,21 @@ __host__ __device__ inline int tiled_phase_stride(int Tq)
 }
 __host__ inline size_t tiled_lds_bytes(int D, int Tq)
 {
-    return (size_t)D * tiled_phase_stride(Tq) * sizeof(float2);
+    return (size_t)D * tiled_phase_stride(Tq) * sizeof(float2) + 16;      // + the scheduler's hand-over slot
 }
 
-// The arctangent table of the fused demodulator (257 floats) lives in the pad slots of
-// polyphase component 0 (slot 9k+8 for R = 8, never touched by staging or the MAC loop):
-// two entries per pad slot, no LDS of its own.
-struct PadTable {
-    float *xsf;
-    __device__ __forceinline__ float &operator[](int i) const
-    {
-        return xsf[((((i >> 1) << TILED_LOGR) + (i >> 1) + TILED_R) << 1) + (i & 1)];
-    }
-};
-struct PadSlots {       // 8-byte entries in the pad slots from number 136 on
+// The arctangent table of the fused demodulator lives in the pad slots of polyphase
+// component 0 (slot 9k+8 for R = 8, never touched by staging or the MAC loop): pad k holds
+// the pair (tab[k], tab[k+1]), so the two entries an interpolation needs come with one
+// 8-byte read and the table takes no LDS of its own.
+struct PadPairs {
     float __attribute__((ext_vector_type(2))) *xs2;
-    __device__ __forceinline__ float __attribute__((ext_vector_type(2))) &operator[](int i) const
+    __device__ __forceinline__ float __attribute__((ext_vector_type(2))) &operator[](int k) const
     {
-        return xs2[((136 + i) << TILED_LOGR) + (136 + i) + TILED_R];
+        return xs2[(k << TILED_LOGR) + k + TILED_R];
     }
 };
-static_assert(((TILED_NT + 2 * TILED_R) >> TILED_LOGR) >= 136 + TILED_NI, "pad slots must hold the arctangent and step tables");
+static_assert(((TILED_NT + 2 * TILED_R + TILED_R) >> TILED_LOGR) >= 256, "pad slots must hold the arctangent table");
 
 bool tiled_supported(int decim, int Tq)
 {
@@ -116,13 +110,13 @@ bool tiled_supported(int decim, int Tq)
 // phases of a tile, written to a buffer of their own (never to an output).
 #ifdef GRHIP_STAMP
 __device__ unsigned long long *g_stamp_buf = nullptr;
-#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now()
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now(), st_begin = st_last
 #define STAMP(k) do { unsigned long long n__ = stamp_now(); st_acc[k] += n__ - st_last; st_last = n__; } while (0)
 __device__ __forceinline__ unsigned long long stamp_now()
 {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");   // constant 100 MHz
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
@@ -196,15 +190,18 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         }
     }
     // arctangent table of the fused demodulator lives in LDS (1 KB)
-    const PadTable s_atan{reinterpret_cast<float *>(xs)};
-    // ... and the staging phasor steps e^{jw 512 i} in the pad slots after it (one per slot)
-    const PadSlots s_step{reinterpret_cast<f32x2 *>(xs)};
+    const PadPairs s_atan{reinterpret_cast<float __attribute__((ext_vector_type(2))) *>(xs)};
+    // staging phasor steps e^{jw 512 i}: wave-uniform and tile independent, kept in VGPRs
+    // (as scalars they do not fit next to the taps and get spilled; read from LDS per round
+    // they put an LDS latency into every round of the staging chain)
+    f32x2 sreg[NI];
     if (PREMIX) {
-        if (t < NI) s_step[t] = reinterpret_cast<const f32x2 *>(a.stab)[t];
-        __syncthreads();        // read by every wave in the first staging pass
+#pragma unroll
+        for (int i = 0; i < NI; ++i) sreg[i] = reinterpret_cast<const f32x2 *>(a.stab)[i];
     }
     if (DEMOD) {
-        for (int i = t; i < 257; i += TILED_THREADS) s_atan[i] = a.atan_tab[i];
+        for (int i = t; i < 256; i += TILED_THREADS)
+            s_atan[i] = (float __attribute__((ext_vector_type(2)))){a.atan_tab[i], a.atan_tab[i + 1]};
     }
 
     // lane constants of the per-wave predecessor computation: taps k = lane + 64 c,
@@ -313,7 +310,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
             if (FP == 1) { e0 = f32x2{pf[i].x, pf[i].y}; e1 = f32x2{pf[i].y, pf[i].z}; }   // (x[u],x[u+1]), (x[u+1],x[u+2])
             if (FP == 2) { e0 = f32x2{pf[i].x, pf[i].z}; e1 = f32x2{pf[i].y, pf[i].w}; }   // (x[u],x[u+2]), (x[u+1],x[u+3])
             if (PREMIX) {
-                const f32x2 si = s_step[i];             // wave-uniform e^{jw 512 i}: LDS broadcast read
+                const f32x2 si = sreg[i];
                 e0 = cmul_pk(e0, cmul_pk(w0l, si));
                 e1 = cmul_pk(e1, cmul_pk(w1l, si));
             }
@@ -333,21 +330,28 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     // tile id = b * n_streams + s (streams fastest): the workgroups that run at the same
     // time work on the same output range of different streams, so the shared rotator
     // phase table is served from L2 instead of being re-read from HBM once per stream.
-    const int adv_b = (int)(gridDim.x / (unsigned)a.n_streams), adv_s = (int)(gridDim.x % (unsigned)a.n_streams);
-    auto advance = [&](int &s, int &b) {
-        s += adv_s; b += adv_b;
-        if (s >= a.n_streams) { s -= a.n_streams; ++b; }
+    //
+    // Scheduling: every workgroup takes tiles blockIdx and blockIdx + G statically, the rest
+    // from a shared counter (a.sched).  The two workgroups of a CU do not run at the same
+    // speed (the SIMDs favour the older wave: measured 10.1 vs 14.7 us per tile), so a static
+    // split leaves the faster half idle for the last sixth of the launch.  The counter is
+    // asked for tile i+2 while tile i is in its MAC loop, so its latency is never waited on.
+    const unsigned total_tiles = (unsigned)tiles_per_stream * (unsigned)a.n_streams;
+    const unsigned G = gridDim.x;
+    unsigned cur = blockIdx.x, nxt = cur + G;
+    auto decode = [&](unsigned id, int &s_, int &b_) {
+        b_ = (int)(id / (unsigned)a.n_streams);
+        s_ = (int)(id - (unsigned)b_ * (unsigned)a.n_streams);
     };
-    int s = (int)(blockIdx.x % (unsigned)a.n_streams), bidx = (int)(blockIdx.x / (unsigned)a.n_streams);
-    // The workgroups that share a CU start together and would stay in lockstep (both in
-    // the MAC loop, then both in the latency-bound phases).  Half of them start late by
-    // about half a tile so that one's MAC loop runs under the other's staging/epilogue.
+    unsigned *sched_slot = reinterpret_cast<unsigned *>(smem + (size_t)D * PS * sizeof(float2));
+    int s = 0, bidx = 0;
+    decode(cur, s, bidx);
     if (a.skew_sleeps > 0) {
         const bool late = a.skew_mode == 1 ? blockIdx.x >= gridDim.x / 2 : (blockIdx.x & 1);
         if (late)
             for (int i = 0; i < a.skew_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    if (bidx < tiles_per_stream) {
+    if (cur < total_tiles) {
         __amdgpu_buffer_rsrc_t rsrc; int voff, off;
         tile_geom(s, bidx, rsrc, voff, off);
         fetch_phases(bidx);
@@ -355,10 +359,10 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     }
     STAMP_DECL;
 
-    while (bidx < tiles_per_stream) {
+    while (cur < total_tiles) {
         const long long n0 = (long long)bidx * NT;
-        int s_nxt = s, b_nxt = bidx;
-        advance(s_nxt, b_nxt);
+        int s_nxt, b_nxt;
+        decode(nxt, s_nxt, b_nxt);
 
         STAMP(7);
         stage(s, bidx);
@@ -370,7 +374,9 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         // loop costs more registers than the 256-VGPR budget has.)
         __amdgpu_buffer_rsrc_t rsrc_n; int voff_n, off_n;
         tile_geom(s_nxt, b_nxt, rsrc_n, voff_n, off_n);
-        if (b_nxt >= tiles_per_stream) voff_n = 0x7ffff000 - NI * LANE_BYTES * TILED_THREADS;   // out of range: zeros, no traffic
+        if (nxt >= total_tiles) voff_n = 0x7ffff000 - NI * LANE_BYTES * TILED_THREADS;   // out of range: zeros, no traffic
+        unsigned nn = nxt + G;
+        if (a.sched && t == 0) nn = atomicAdd(a.sched, 1u) + 2u * G;       // arrives during the MAC loop
 #if GRHIP_EXP & 4
         fetch(rsrc_n, voff_n, -1);
 #endif
@@ -566,8 +572,11 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
             float d[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                d[r] = (a.ablate & 4) ? acc[r].x + prev.y
-                       : DIRECT ? quad_demod_fast(acc[r], prev, a.gain, s_atan) : quad_demod_one(acc[r], prev, a.gain, s_atan);
+#if GRHIP_EXP & 16
+                d[r] = acc[r].x + prev.y;
+#else
+                d[r] = DIRECT ? quad_demod_fast(acc[r], prev, a.gain, s_atan) : quad_demod_one(acc[r], prev, a.gain, s_atan);
+#endif
                 prev = acc[r];
             }
             float *__restrict__ o = a.d_out + s * a.d_stride;
@@ -588,16 +597,29 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
                     if (nl + r == last) a.y_last[s] = DIRECT ? cmul_fma(acc[r], a.vtab[t * R + r]) : acc[r];
             }
         }
-        if (b_nxt < tiles_per_stream) fetch_phases(b_nxt);      // for the next tile's epilogue
+        if (nxt < total_tiles) fetch_phases(b_nxt);      // for the next tile's epilogue
+        if (a.sched && t == 0) sched_slot[0] = nn;
         STAMP(5);
         __syncthreads();        // xs is rewritten by the next tile
         STAMP(6);
+        if (a.sched) nn = sched_slot[0];
+        cur = nxt; nxt = nn;
         s = s_nxt; bidx = b_nxt;
+    }
+    // the last workgroup out re-arms the counter for the next launch
+    if (a.sched && t == 0) {
+        __threadfence();
+        if (atomicAdd(a.sched + 1, 1u) == G - 1) {
+            a.sched[0] = 0;
+            a.sched[1] = 0;
+            __threadfence();
+        }
     }
 #ifdef GRHIP_STAMP
     if ((t & 63) == 0 && g_stamp_buf) {
-        unsigned long long *o = g_stamp_buf + ((size_t)blockIdx.x * (TILED_THREADS / 64) + (t >> 6)) * 8;
+        unsigned long long *o = g_stamp_buf + ((size_t)blockIdx.x * (TILED_THREADS / 64) + (t >> 6)) * 10;
         for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+        o[8] = st_begin; o[9] = stamp_now();
     }
 #endif
 }
@@ -622,7 +644,9 @@ static int launch_tiled_inst(const FirTiledArgs &a, hipStream_t st)
         g_num_cus = n > 0 ? n : 256;
     }
     const long long tiles = ((a.n_out + TILED_NT - 1) / TILED_NT) * a.n_streams;
-    long long grid = (long long)TILED_WG_PER_CU * g_num_cus;   // persistent workgroups
+    static int wg_per_cu = 0;
+    if (!wg_per_cu) { const char *e = getenv("GRHIP_WGPCU"); wg_per_cu = e ? atoi(e) : TILED_WG_PER_CU; }   // tuning knob
+    long long grid = (long long)wg_per_cu * g_num_cus;   // persistent workgroups
     if (grid > tiles) grid = tiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TILED_THREADS), lds, st, a);
     GRHIP_HIP(hipGetLastError());
@@ -658,7 +682,7 @@ static int launch_tiled_d(bool ctaps, bool premix, int epi, const FirTiledArgs &
 }
 
 #ifdef GRHIP_STAMP
-// debug hook (not part of the ABI): where the stamp sums go; needs 8 u64 per wave
+// debug hook (not part of the ABI): where the stamp sums go; needs 10 u64 per wave
 extern "C" __attribute__((visibility("default"))) int grdbg_set_stamp_buffer(void *d_buf)
 {
     unsigned long long *p = (unsigned long long *)d_buf;

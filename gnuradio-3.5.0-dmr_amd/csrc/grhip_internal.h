@@ -50,6 +50,20 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// the two counters of the tiled kernel's tile queue: zeroed once, re-armed by every launch
+struct SchedBuf {
+    DevBuf b;
+    unsigned *get()
+    {
+        if (!b.p) {
+            if (b.reserve(2 * sizeof(unsigned)) != GRHIP_OK) return nullptr;
+            if (hipMemset(b.p, 0, 2 * sizeof(unsigned)) != hipSuccess) { b.release(); return nullptr; }
+        }
+        return b.as<unsigned>();
+    }
+    void release() { b.release(); }
+};
+
 // ---- base of every block handle -------------------------------------------
 struct HandleBase {
     int device = 0;

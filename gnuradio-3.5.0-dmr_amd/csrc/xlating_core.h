@@ -33,6 +33,7 @@ struct XlatingCore {
     int Tq = 0;
     bool use_tiled = false, premix = false;
     DevBuf scratch_y;
+    SchedBuf sched;                             // tile queue of the tiled kernel (one launch at a time per handle)
 
     // rotator table: phases of outputs [tab_start, tab_start+tab_len)
     long long pos = 0;                          // outputs produced since construction/reset

@@ -2,11 +2,16 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#ifndef ITER_SCALE
+#define ITER_SCALE 1
+#endif
 typedef float float2_ __attribute__((ext_vector_type(2)));
 
 template <bool PK, bool SGPR_OP>
-__global__ void __launch_bounds__(256) k(float *out, const float *taps, int iters)
+__global__ void __launch_bounds__(256) k(float *out, const float *taps, int iters, unsigned long long *ticks)
 {
+    unsigned long long t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
     float2_ a[16];
     for (int i = 0; i < 16; ++i) a[i] = (float2_){(float)threadIdx.x * 1e-3f + i, 1.0f};
     float2_ x = (float2_){1.0001f, 0.9999f};
@@ -29,6 +34,9 @@ __global__ void __launch_bounds__(256) k(float *out, const float *taps, int iter
     }
     float s = 0;
     for (int i = 0; i < 16; ++i) s += a[i].x + a[i].y;
+    unsigned long long t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) : "v"(s) : "memory");
+    if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -41,13 +49,15 @@ void run(const char *name, int blocks_per_cu)
     hipMalloc(&taps, 64);
     float h[2] = {0.999f, 1.001f};
     hipMemcpy(taps, h, 8, hipMemcpyHostToDevice);
-    int iters = 20000;
+    unsigned long long *ticks;
+    hipMalloc(&ticks, 8);
+    int iters = 20000 * ITER_SCALE;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    k<PK, true><<<ncu * blocks_per_cu, 256>>>(out, taps, 100);
+    k<PK, true><<<ncu * blocks_per_cu, 256>>>(out, taps, 100, ticks);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<PK, true><<<ncu * blocks_per_cu, 256>>>(out, taps, iters);
+    k<PK, true><<<ncu * blocks_per_cu, 256>>>(out, taps, iters, ticks);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -57,12 +67,17 @@ void run(const char *name, int blocks_per_cu)
     double lane_fma = (double)iters * 64 * 2 * 256.0 * ncu * blocks_per_cu;
     printf("%-10s waves/SIMD %d: %.3f ms  -> %.2f ns per wave-instr per SIMD, %.1f TFLOP/s (fma=2)\n", name,
            blocks_per_cu, ms, ms * 1e6 / (inst_per_wave * waves_per_simd), lane_fma * 2 / (ms * 1e-3) / 1e12);
-    hipFree(out); hipFree(taps);
+    unsigned long long tk = 0;
+    hipMemcpy(&tk, ticks, 8, hipMemcpyDeviceToHost);
+    printf("           s_memtime: %llu ticks = %.1f MHz; %.2f ticks per wave-instr of wave 0\n", tk, tk / (ms * 1e3),
+           (double)tk / inst_per_wave);
+    hipFree(out); hipFree(taps); hipFree(ticks);
 }
 
+static int ITER_SCALE_dummy;
 int main()
 {
-    for (int b : {1, 2, 4, 8}) run<true>("pk_fma", b);
-    for (int b : {1, 2, 4, 8}) run<false>("fma", b);
+    for (int b : {1, 2, 4}) run<true>("pk_fma", b);
+    for (int b : {1, 2}) run<false>("fma", b);
     return 0;
 }
