@@ -74,7 +74,8 @@ __device__ __forceinline__ float fast_atan2f(float y, float x, Tab tab)
     float alpha = z * 256.0f - 0.5f;                       // :151
     int index = (int)alpha;
     index = index < 0 ? 0 : (index > 255 ? 255 : index);   // no-op for finite z >= TAN_MAP_RES; keeps the rest in bounds
-    alpha -= (float)index;
+    if (EXACT_DIV) alpha -= (float)index;
+    else alpha = __builtin_amdgcn_fractf(alpha);           // same value wherever the interpolation is used (alpha >= 0)
     float t0, t1;
     atan_pair(tab, index, t0, t1);
     float interp = t0;
@@ -88,7 +89,7 @@ __device__ __forceinline__ float fast_atan2f(float y, float x, Tab tab)
     const float sb = (big != xpos) ? -base_angle : base_angle;
     const float ap = q + sb;
     float angle = ypos ? ap : -ap;
-    return ((y == 0.0f) && (x == 0.0f)) ? 0.0f : angle;    // :133
+    return (den == 0.0f) ? 0.0f : angle;                   // :133 (y == 0 && x == 0  <=>  max(|y|,|x|) == 0)
 }
 
 // one output of gr_quadrature_demod_cf::work (general/gr_quadrature_demod_cf.cc:57-59)
@@ -103,7 +104,7 @@ __device__ __forceinline__ float quad_demod_one(float2 cur, float2 prev, float g
 template <class Tab>
 __device__ __forceinline__ float quad_demod_fast(float2 cur, float2 prev, float gain, Tab tab)
 {
-    const float2 product = cmul_fma(cur, make_float2(prev.x, -prev.y));
+    const f32x2_t product = cmul_pk(f32x2_t{cur.x, cur.y}, f32x2_t{prev.x, -prev.y});
     return gain * fast_atan2f<false>(product.y, product.x, tab);
 }
 

@@ -170,12 +170,11 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     // lane constants of the pre-mix phasor: W[v] = e^{jw(v-D)}, v = 2t-1, 2t, 2t+1
     // (table entry v+1 holds W[v], v = -1 .. 511)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 wA{1.f, 0.f}, wB = wA, wC = wA;
+    f32x2 wA{1.f, 0.f}, wB = wA;
     if (PREMIX) {
         const f32x2 *wt = reinterpret_cast<const f32x2 *>(a.wtab);
         wA = wt[2 * t];
         wB = wt[2 * t + 1];
-        wC = wt[2 * t + 2];
     }
 
     // per-lane output phase corrections of the pre-mix form (tile independent)
@@ -191,14 +190,14 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     }
     // arctangent table of the fused demodulator lives in LDS (1 KB)
     const PadPairs s_atan{reinterpret_cast<float __attribute__((ext_vector_type(2))) *>(xs)};
-    // staging phasor steps e^{jw 512 i}: wave-uniform and tile independent, kept in VGPRs
-    // (as scalars they do not fit next to the taps and get spilled; read from LDS per round
-    // they put an LDS latency into every round of the staging chain)
-    f32x2 sreg[NI];
-    if (PREMIX) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) sreg[i] = reinterpret_cast<const f32x2 *>(a.stab)[i];
-    }
+    // Pre-mix phasor of the lane's first sample in every staging round, W[ub + 512 i] =
+    // (lane constant) x (step e^{jw 512 i}): tile independent, built once, kept in VGPRs
+    // (36 of them; the second sample's phasor is one more product with e^{jw}).  They depend
+    // on the parity `off` of the stream's 16-byte alignment, which is the same for every
+    // tile of a launch unless the stream stride is odd: rebuilt when it changes.
+    f32x2 W0[NI];
+    const f32x2 wstep = cmul_pk(wB, f32x2{wA.x, -wA.y});      // e^{jw}
+    int w_off = -1;
     if (DEMOD) {
         for (int i = t; i < 256; i += TILED_THREADS)
             s_atan[i] = (float __attribute__((ext_vector_type(2)))){a.atan_tab[i], a.atan_tab[i + 1]};
@@ -295,7 +294,13 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     auto stage = [&](int s, int b) {
         __amdgpu_buffer_rsrc_t rsrc; int voff, off;
         tile_geom(s, b, rsrc, voff, off);
-        const f32x2 w0l = off ? wA : wB, w1l = off ? wB : wC;
+        if (PREMIX && off != w_off) {       // wave-uniform, first tile only in practice
+            const f32x2 w0l = off ? wA : wB;
+            const f32x2 *st = reinterpret_cast<const f32x2 *>(a.stab);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) W0[i] = cmul_pk(w0l, st[i]);
+            w_off = off;
+        }
         const int ub = -off + 2 * t;
         constexpr int SLOT_STEP = (2 * TILED_THREADS / D) + (2 * TILED_THREADS / D) / R;
         constexpr int FULL = NT * D / (2 * TILED_THREADS);     // rounds that lie inside the tile for every lane
@@ -310,9 +315,8 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
             if (FP == 1) { e0 = f32x2{pf[i].x, pf[i].y}; e1 = f32x2{pf[i].y, pf[i].z}; }   // (x[u],x[u+1]), (x[u+1],x[u+2])
             if (FP == 2) { e0 = f32x2{pf[i].x, pf[i].z}; e1 = f32x2{pf[i].y, pf[i].w}; }   // (x[u],x[u+2]), (x[u+1],x[u+3])
             if (PREMIX) {
-                const f32x2 si = sreg[i];
-                e0 = cmul_pk(e0, cmul_pk(w0l, si));
-                e1 = cmul_pk(e1, cmul_pk(w1l, si));
+                e0 = cmul_pk(e0, W0[i]);
+                e1 = cmul_pk(e1, cmul_pk(W0[i], wstep));
             }
             if (i == 0) {
                 if (u >= 0) dst0[0] = e0;

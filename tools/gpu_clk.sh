@@ -3,14 +3,14 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_clk
 rm -rf $O; mkdir -p $O
-for w in 1 2; do
+for w in 2; do
   export GRHIP_WGPCU=$w
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $O/w$w -- python3 $R/bench.py --steps 6 --warmup 2 --captures 16 --no-cpu-baseline > $O/bench_w$w.log 2>&1
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $O/w$w -- python3 $R/bench.py --steps 6 --warmup 2 --captures 64 --ramp-ms 300 --no-cpu-baseline > $O/bench_w$w.log 2>&1
 done
 cd $O
 python3 - <<'PY'
 import csv, glob, collections
-for w in (1,2):
+for w in (2,):
     acc=collections.defaultdict(float); cnt=collections.Counter()
     for f in glob.glob("w%d/**/*counter_collection.csv"%w, recursive=True):
         for r in csv.DictReader(open(f)):
