@@ -208,15 +208,37 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         a.x = d_in; a.x_stride = x_stride; a.n_in = n_in; a.n_lo = n_lo;
         a.hp = d_hp.as<float>(); a.Tq = Tq; a.n_out = n_out;
         a.wtab = d_wtab.as<float2>(); a.stab = d_stab.as<float2>(); a.vtab = d_vtab.as<float2>(); a.gtab = gtab;
-        a.y_out = d_y; a.d_out = d_demod; a.gain = gain;
-        a.y_stride = out_stride; a.d_stride = out_stride;
-        a.y_prev = y_prev; a.y_last = y_last; a.atan_tab = atan_tab;
+        a.gain = gain; a.atan_tab = atan_tab;
         a.sched = sched.get();
-        uintptr_t o = demod ? (uintptr_t)d_demod : (uintptr_t)d_y;
-        a.vec_store = (o & 15) == 0 && ((out_stride * (demod ? 4 : 8)) & 15) == 0;
-        rc = launch_fir_tiled(decim, !premix, premix, direct ? EPI_DEMOD : demod ? EPI_ROTATE_DEMOD : EPI_ROTATE, a,
-                              n_streams, st);
-        if (rc) return rc;
+        if (direct || !demod) {
+            a.y_out = d_y; a.d_out = d_demod;
+            a.y_stride = out_stride; a.d_stride = out_stride;
+            a.y_prev = y_prev; a.y_last = y_last;
+            uintptr_t o = demod ? (uintptr_t)d_demod : (uintptr_t)d_y;
+            a.vec_store = (o & 15) == 0 && ((out_stride * (demod ? 4 : 8)) & 15) == 0;
+            rc = launch_fir_tiled(decim, !premix, premix, direct ? EPI_DEMOD : EPI_ROTATE, a, n_streams, st);
+            if (rc) return rc;
+        } else {
+            // complex prototype taps: the tiled kernel writes y (with one slot in front of every
+            // stream for the demodulator's previous sample), the demodulator is a second kernel
+            const long long ys = n_out + 1;
+            rc = scratch_y.reserve((size_t)ys * n_streams * sizeof(float2));
+            if (rc) return rc;
+            float2 *sy = scratch_y.as<float2>();
+            if (y_prev) GRHIP_HIP(hipMemcpy2DAsync(sy, ys * sizeof(float2), y_prev, sizeof(float2), sizeof(float2),
+                                                   n_streams, hipMemcpyDeviceToDevice, st));
+            else GRHIP_HIP(hipMemset2DAsync(sy, ys * sizeof(float2), 0, sizeof(float2), n_streams, st));
+            a.y_out = sy + 1; a.y_stride = ys;
+            a.vec_store = 0;
+            rc = launch_fir_tiled(decim, true, false, EPI_ROTATE, a, n_streams, st);
+            if (rc) return rc;
+            for (int s = 0; s < n_streams; ++s) {
+                rc = launch_quad_demod(sy + s * ys, d_demod + s * out_stride, n_out, gain, atan_tab, st);
+                if (rc) return rc;
+            }
+            if (y_last) GRHIP_HIP(hipMemcpy2DAsync(y_last, sizeof(float2), sy + n_out, ys * sizeof(float2), sizeof(float2),
+                                                   n_streams, hipMemcpyDeviceToDevice, st));
+        }
     } else {
         if (n_streams != 1 || n_lo != 0)
             return fail(GRHIP_EINVAL, "generic-order path runs one stream with explicit history");

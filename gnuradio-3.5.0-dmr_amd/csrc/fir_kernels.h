@@ -48,7 +48,7 @@ struct FirTiledArgs {
 // and the last two factors are e^{-jwD} and the rotator step e^{+jwD}(1 + O(1e-7)), so neither
 // the phase correction nor the rotator table is needed; the carry (y_prev / y_last) is kept
 // in the frame of the un-rotated composite FIR output, acc * v.
-enum { EPI_NONE = 0, EPI_ROTATE = 1, EPI_ROTATE_DEMOD = 2, EPI_DEMOD = 3 };
+enum { EPI_NONE = 0, EPI_ROTATE = 1, EPI_ROTATE_DEMOD = 2 /* retired: rotate, then the stand-alone demodulator */, EPI_DEMOD = 3 };
 
 // returns GRHIP_OK or <0 ; `decim` must be one of tiled_supported_decim().
 bool tiled_supported(int decim, int ntaps_padded_per_phase);

@@ -55,7 +55,6 @@ static_assert(TILED_R == 8 || TILED_R == 4, "R must be 4 or 8");
 #define GRHIP_TILED_THREADS 256
 #endif
 constexpr int TILED_THREADS = GRHIP_TILED_THREADS;
-constexpr int TILED_WPW = 64 * TILED_R;           // outputs per wave
 constexpr int TILED_NT = TILED_THREADS * TILED_R;
 constexpr int TILED_WG_PER_CU = (TILED_R == 8 ? 2 : 3) * 256 / TILED_THREADS;
 constexpr int TILED_NI = TILED_R == 8 ? 18 : 11;       // 16-byte loads per lane per tile (upper bound)
@@ -155,16 +154,28 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     constexpr bool DEMOD = EPI == EPI_ROTATE_DEMOD || EPI == EPI_DEMOD;    // fused quadrature demodulator
     constexpr bool DIRECT = EPI == EPI_DEMOD;                              // ... on the pre-mixed accumulators
     static_assert(!DIRECT || PREMIX, "EPI_DEMOD is the pre-mix form's epilogue");
+    static_assert(EPI != EPI_ROTATE_DEMOD, "the only fused demodulator is EPI_DEMOD");
+    // The demodulator needs y[n-1] next to y[n].  Inside a wave that is the neighbouring
+    // lane's last accumulator (one DPP shift); across waves and tiles it is made local by
+    // OVERLAP: lane 0 of every wave recomputes the R outputs of the lane before it (the
+    // previous wave's or the previous tile's last lane) and stores nothing.  A tile
+    // therefore covers NTC = NT - 3R distinct outputs, NTE = NTC - R of them new: 1.6 %
+    // more MACs instead of a reduction over the taps, its LDS reads and its latency.
+    constexpr int WAVES = TILED_THREADS / 64;
+    constexpr int OVL = DIRECT ? TILED_R : 0;
+    constexpr int NTC = TILED_NT - OVL * (WAVES - 1);
+    constexpr int NTE = NTC - OVL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *xs = (float2 *)smem;
 
     const int t = threadIdx.x;
     const int Tq = a.Tq;
     const int PS = tiled_phase_stride(Tq);
-    const int Lu = (NT + Tq) * D;                   // samples per tile, u = 0 <-> (n0-1)*D
+    const int Lu = (NTC + Tq) * D;                  // samples per tile, u = 0 <-> (first covered output - 1)*D
+    const int tl = t - (OVL ? (t >> 6) : 0);        // lane's place in the tile: outputs tl*R .. tl*R+R-1 of the covered range
     // tiles are numbered (stream, tile-in-stream); the pair is advanced incrementally
     // (a 64-bit division per tile costs ~150 scalar instructions)
-    const int tiles_per_stream = (int)((a.n_out + NT - 1) / NT);
+    const int tiles_per_stream = (int)((a.n_out + NTE - 1) / NTE);
     const cfloat_p hp = (cfloat_p)a.hp;             // phase-major taps, padded by R entries
 
     // lane constants of the pre-mix phasor: W[v] = e^{jw(v-D)}, v = 2t-1, 2t, 2t+1
@@ -203,27 +214,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
             s_atan[i] = (float __attribute__((ext_vector_type(2)))){a.atan_tab[i], a.atan_tab[i + 1]};
     }
 
-    // lane constants of the per-wave predecessor computation: taps k = lane + 64 c,
-    // and the wave's phase correction of the pre-mix form
-    constexpr int PB = 8;
-    const bool pb_in_regs = Tq * D <= 64 * PB;
-    float hb[PB * TW];
-    float2 vb = make_float2(1.f, 0.f);
-    if (DEMOD) {
-#pragma unroll
-        for (int c = 0; c < PB; ++c) {
-            const int k = (t & 63) + 64 * c;
-            const int kk = (k < Tq * D && pb_in_regs) ? k : 0;
-            const int idx = (kk & (D - 1)) * Tq + (kk >> LOGD);
-#pragma unroll
-            for (int w2 = 0; w2 < TW; ++w2) hb[c * TW + w2] = a.hp[idx * TW + w2];
-        }
-        const int jb = TILED_WPW * (t >> 6);           // tile-local index + 1 of the predecessor
-        if (PREMIX && !DIRECT) vb = a.vtab[jb == 0 ? NT : jb - 1];
-    }
-
     float4 pf[NI];
-    float2 gb = make_float2(1.f, 0.f);     // rotator phase of the wave's predecessor output
     float2 gq[R];                          // rotator phases of the lane's outputs
 
     // tile -> buffer descriptor of its stream + byte offset of the lane's first pair.
@@ -235,7 +226,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int LANE_BYTES = FP ? 8 : 16;         // bytes between the loads of neighbouring lanes
     auto tile_geom = [&](int s, int b, __amdgpu_buffer_rsrc_t &rsrc, int &voff, int &off) {
-        const long long g0 = ((long long)b * NT - 1) * D - a.n_lo;        // tile start relative to the first real item
+        const long long g0 = ((long long)b * NTE - OVL - 1) * D - a.n_lo;   // tile start relative to the first real item
         if (FP) {
             // items are floats; strides and counts of the launch are in floats
             const float *xf = reinterpret_cast<const float *>(a.x) + (long long)s * a.x_stride + a.n_lo;
@@ -265,10 +256,6 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
             for (int r = 0; r < R; ++r) {
                 const int j = t * R + r;
                 gq[r] = gt[j < lim ? j : lim];
-            }
-            if (EPI == EPI_ROTATE_DEMOD) {
-                const int jb = TILED_WPW * (t >> 6) - 1;
-                gb = (b == 0 && jb < 0) ? make_float2(1.f, 0.f) : gt[jb];
             }
         }
     };
@@ -303,7 +290,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         }
         const int ub = -off + 2 * t;
         constexpr int SLOT_STEP = (2 * TILED_THREADS / D) + (2 * TILED_THREADS / D) / R;
-        constexpr int FULL = NT * D / (2 * TILED_THREADS);     // rounds that lie inside the tile for every lane
+        constexpr int FULL = NTC * D / (2 * TILED_THREADS);    // rounds that lie inside the tile for every lane
         const int mm0 = (ub >> LOGD) - 1 + R, p0 = ub & (D - 1);
         const int mm1 = ((ub + 1) >> LOGD) - 1 + R, p1 = (ub + 1) & (D - 1);
         f32x2 *dst0 = reinterpret_cast<f32x2 *>(xs) + p0 * PS + mm0 + (mm0 >> LOGR);
@@ -364,7 +351,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
     STAMP_DECL;
 
     while (cur < total_tiles) {
-        const long long n0 = (long long)bidx * NT;
+        const long long n0 = (long long)bidx * NTE - OVL;     // first covered output
         int s_nxt, b_nxt;
         decode(nxt, s_nxt, b_nxt);
 
@@ -386,66 +373,6 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
 #endif
         STAMP(2);
 
-        // ---------------- predecessor of each WAVE's first output (fused demod) -----
-        // y[n0 + 512 w - 1] is recomputed by the 64 lanes of wave w (tree-order sum over
-        // the taps): no exchange between waves or workgroups, no barrier.  Its taps and
-        // phase factors are lane constants / were fetched a tile ahead, so nothing here
-        // queues behind the prefetch that was just issued.
-        float2 yb = make_float2(0.f, 0.f);
-        if (DEMOD) {
-            const int wv = t >> 6, ln = t & 63;
-            if (bidx == 0 && wv == 0) {
-                yb = a.y_prev ? a.y_prev[s] : make_float2(0.f, 0.f);
-                if (DIRECT) {           // carried in the acc * v frame; v[-1] = vtab[NT]
-                    const float2 vm = a.vtab[NT];
-                    yb = cmul_fma(yb, make_float2(vm.x, -vm.y));
-                }
-            } else {
-                float2 part = make_float2(0.f, 0.f);
-                const int mb = TILED_WPW * wv + R - 1;         // mm of the output's first sample
-                if (pb_in_regs) {
-#pragma unroll
-                    for (int c = 0; c < PB; ++c) {
-                        const int k = ln + 64 * c;
-                        if (k < Tq * D) {
-                            const int p = k & (D - 1), q = k >> LOGD;
-                            const int mm = mb + q;
-                            const float2 xv = xs[p * PS + mm + (mm >> LOGR)];
-                            if (CTAPS) {
-                                part.x = __builtin_fmaf(hb[2 * c], xv.x, part.x);
-                                part.x = __builtin_fmaf(-hb[2 * c + 1], xv.y, part.x);
-                                part.y = __builtin_fmaf(hb[2 * c], xv.y, part.y);
-                                part.y = __builtin_fmaf(hb[2 * c + 1], xv.x, part.y);
-                            } else {
-                                part.x = __builtin_fmaf(hb[c], xv.x, part.x);
-                                part.y = __builtin_fmaf(hb[c], xv.y, part.y);
-                            }
-                        }
-                    }
-                } else {
-                    for (int k = ln; k < Tq * D; k += 64) {
-                        const int p = k & (D - 1), q = k >> LOGD;
-                        const int mm = mb + q;
-                        const float2 xv = xs[p * PS + mm + (mm >> LOGR)];
-                        if (CTAPS) {
-                            const float hr = a.hp[2 * (p * Tq + q)], hi = a.hp[2 * (p * Tq + q) + 1];
-                            part.x = __builtin_fmaf(hr, xv.x, part.x);
-                            part.x = __builtin_fmaf(-hi, xv.y, part.x);
-                            part.y = __builtin_fmaf(hr, xv.y, part.y);
-                            part.y = __builtin_fmaf(hi, xv.x, part.y);
-                        } else {
-                            const float h = a.hp[p * Tq + q];
-                            part.x = __builtin_fmaf(h, xv.x, part.x);
-                            part.y = __builtin_fmaf(h, xv.y, part.y);
-                        }
-                    }
-                }
-                yb = make_float2(wave_sum(part.x), wave_sum(part.y));
-                if (PREMIX && !DIRECT) yb = cmul_fma(yb, vb);
-                if (ROT) yb = cmul_ref(yb, gb);
-            }
-        }
-
         STAMP(3);
         // ---------------- MAC loop: R outputs per lane -----------------------------
         // The lane's samples of a pass (polyphase component p) come in blocks of R
@@ -459,7 +386,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         f32x2 av[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) av[r] = f32x2{0.f, 0.f};
-        const int lane_base = (t + 1) * R + (t + 1);       // slot of mm = (t+1)R
+        const int lane_base = (tl + 1) * R + (tl + 1);     // slot of mm = (tl+1)R
         const int nb = Tq >> LOGR;                         // steps per pass
         tapvec hcur = *reinterpret_cast<const tapvec __attribute__((address_space(4))) *>(hp);
 
@@ -544,7 +471,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
 
         STAMP(4);
         // ---------------- epilogue ---------------------------------------------------
-        const long long nl = n0 + (long long)t * R;          // first output of this lane
+        const long long nl = n0 + (long long)tl * R;         // first output of this lane
         if (PREMIX && !DIRECT) {
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = cmul_fma(acc[r], vreg[r]);
@@ -567,38 +494,47 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
                     if (nl + r < a.n_out) y[nl + r] = acc[r];
             }
         } else {
-            // previous output for r = 0: the neighbouring lane's last one (DPP shift);
-            // lane 0 of every wave takes the wave's recomputed predecessor
+            // previous output for r = 0: the neighbouring lane's last one.  Lane 0 of a wave
+            // holds the overlap outputs: it only hands its last one on.  At the start of a
+            // stream that one is the carry of the previous call (acc * v frame, tile-local
+            // index R-1), or zero for a fresh block.
+            if (bidx == 0 && t == 0) {
+                float2 yp = a.y_prev ? a.y_prev[s] : make_float2(0.f, 0.f);
+                const float2 vm = a.vtab[R - 1];
+                acc[R - 1] = cmul_fma(yp, make_float2(vm.x, -vm.y));
+            }
             float2 prev;
             prev.x = __shfl_up(acc[R - 1].x, 1);
             prev.y = __shfl_up(acc[R - 1].y, 1);
-            if ((t & 63) == 0) prev = yb;
             float d[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
 #if GRHIP_EXP & 16
                 d[r] = acc[r].x + prev.y;
 #else
-                d[r] = DIRECT ? quad_demod_fast(acc[r], prev, a.gain, s_atan) : quad_demod_one(acc[r], prev, a.gain, s_atan);
+                d[r] = quad_demod_fast(acc[r], prev, a.gain, s_atan);
 #endif
                 prev = acc[r];
             }
             float *__restrict__ o = a.d_out + s * a.d_stride;
-            if (a.vec_store && nl + R <= a.n_out) {
-                float4 *dst = reinterpret_cast<float4 *>(o + nl);
+            const bool owner = (t & 63) != 0;               // lane 0 of a wave: overlap only
+            if (owner) {
+                if (a.vec_store && nl + R <= a.n_out) {
+                    float4 *dst = reinterpret_cast<float4 *>(o + nl);
 #pragma unroll
-                for (int r = 0; r < R; r += 4) dst[r >> 2] = make_float4(d[r], d[r + 1], d[r + 2], d[r + 3]);
-            } else {
+                    for (int r = 0; r < R; r += 4) dst[r >> 2] = make_float4(d[r], d[r + 1], d[r + 2], d[r + 3]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (nl + r < a.n_out) o[nl + r] = d[r];
-            }
-            // carry for the next call: the last output of the stream
-            const long long last = a.n_out - 1;
-            if (a.y_last && last >= nl && last < nl + R) {
+                    for (int r = 0; r < R; ++r)
+                        if (nl + r < a.n_out) o[nl + r] = d[r];
+                }
+                // carry for the next call: the last output of the stream
+                const long long last = a.n_out - 1;
+                if (a.y_last && last >= nl && last < nl + R) {
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (nl + r == last) a.y_last[s] = DIRECT ? cmul_fma(acc[r], a.vtab[t * R + r]) : acc[r];
+                    for (int r = 0; r < R; ++r)
+                        if (nl + r == last) a.y_last[s] = cmul_fma(acc[r], a.vtab[tl * R + r]);
+                }
             }
         }
         if (nxt < total_tiles) fetch_phases(b_nxt);      // for the next tile's epilogue
@@ -647,7 +583,8 @@ static int launch_tiled_inst(const FirTiledArgs &a, hipStream_t st)
         GRHIP_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
         g_num_cus = n > 0 ? n : 256;
     }
-    const long long tiles = ((a.n_out + TILED_NT - 1) / TILED_NT) * a.n_streams;
+    constexpr int NEW_PER_TILE = EPI == EPI_DEMOD ? TILED_NT - TILED_R * (TILED_THREADS / 64) : TILED_NT;
+    const long long tiles = ((a.n_out + NEW_PER_TILE - 1) / NEW_PER_TILE) * a.n_streams;
     static int wg_per_cu = 0;
     if (!wg_per_cu) { const char *e = getenv("GRHIP_WGPCU"); wg_per_cu = e ? atoi(e) : TILED_WG_PER_CU; }   // tuning knob
     long long grid = (long long)wg_per_cu * g_num_cus;   // persistent workgroups
@@ -664,14 +601,12 @@ static int launch_tiled_d(bool ctaps, bool premix, int epi, const FirTiledArgs &
         switch (epi) {
         case EPI_NONE: return launch_tiled_inst<D, true, false, EPI_NONE>(a, st);
         case EPI_ROTATE: return launch_tiled_inst<D, true, false, EPI_ROTATE>(a, st);
-        case EPI_ROTATE_DEMOD: return launch_tiled_inst<D, true, false, EPI_ROTATE_DEMOD>(a, st);
-        default: return fail(GRHIP_EINVAL, "complex taps have no direct demodulator epilogue");
+        default: return fail(GRHIP_EINVAL, "complex taps have no fused demodulator epilogue");
         }
     }
     if (premix) {
         switch (epi) {
         case EPI_ROTATE: return launch_tiled_inst<D, false, true, EPI_ROTATE>(a, st);
-        case EPI_ROTATE_DEMOD: return launch_tiled_inst<D, false, true, EPI_ROTATE_DEMOD>(a, st);
         case EPI_DEMOD: return launch_tiled_inst<D, false, true, EPI_DEMOD>(a, st);
         default: return fail(GRHIP_EINVAL, "premix needs a rotate epilogue");
         }

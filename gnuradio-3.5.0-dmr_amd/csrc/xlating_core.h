@@ -71,8 +71,7 @@ struct XlatingCore {
     // fused demodulator on the pre-mixed accumulators (EPI_DEMOD): FAST mode, real prototype taps
     bool demod_is_direct(int mode, bool demod) const
     {
-        static const bool off = getenv("GRHIP_NO_DIRECT") != nullptr;     // A/B knob (profiling only)
-        return !off && demod && mode == GRHIP_MODE_FAST && use_tiled && premix;
+        return demod && mode == GRHIP_MODE_FAST && use_tiled && premix;
     }
     // d_in item 0 = input[0] of output 0 (oldest history item); items with index
     // < n_lo or >= n_in read as zero.  n_streams > 1: stream s at d_in + s*x_stride,

@@ -61,22 +61,4 @@ def bits_equal(a, b):
     return bool(np.array_equal(a.view(np.uint8), b.view(np.uint8)))
 
 
-def demod_close(got, ref, skip=64, tol=1e-5):
-    """Tolerance check for quadrature-demod outputs of the FAST path.
-
-    Steady state (after the FIR's start-up transient of ntaps/decim = 64 outputs):
-    |got - ref| <= tol * max|ref| there -- the north-star 1e-5, relative to the
-    demodulator's output range.  Inside the transient the FIR output climbs from 0, the
-    demodulator takes the angle of numbers that are ~1e-3 of full scale, and an angle is
-    only as accurate as |dy|/|y|; there the check is 1e-2 of the output range (it still
-    catches a wrong sample, not rounding).  Returns (ok, worst_steady_relative_error)."""
-    got = np.asarray(got); ref = np.asarray(ref)
-    if got.shape != ref.shape:
-        return False, float("inf")
-    if len(ref) <= skip:
-        return bool(np.abs(got - ref).max() <= 1e-2 * max(np.abs(ref).max(), 1e-30)), 0.0
-    s = float(np.abs(ref[skip:]).max())
-    e_steady = float(np.abs(got[skip:] - ref[skip:]).max())
-    e_trans = float(np.abs(got[:skip] - ref[:skip]).max())
-    full = float(np.abs(ref).max())
-    return (e_steady <= tol * s) and (e_trans <= 1e-2 * full), e_steady / s
+from parity_util import demod_close  # noqa: E402,F401  (shared with __graft_entry__.smoke)

@@ -269,6 +269,21 @@ def test_fused_xlating_demod_mode_switch_mid_stream(gpu, po, wl):
     assert ok, worst
 
 
+def test_fused_xlating_demod_complex_prototype(gpu, po, wl):
+    """complex prototype taps: no pre-mix form, the tiled kernel writes y and the
+    stand-alone demodulator follows (chunked, so the carry crosses calls)"""
+    c = wl.CFG2
+    n = 300_000
+    x = wl.fsk4_capture(n, stream_id=11)
+    rng = np.random.default_rng(5)
+    proto = (wl.cfg2_proto_taps().real * np.exp(1j * 0.01 * np.arange(256))).astype(np.complex64)
+    ref = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], x)
+    blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
+    got = gpu.run_sync_block(blk, x, chunk=50_000)
+    ok, worst = demod_close(got, ref)
+    assert ok, worst
+
+
 def test_unfused_pipeline_equals_fused(gpu, po, wl):
     """tb.connect(xlating, demod) as two blocks vs the fused hier block"""
     c = wl.CFG2
