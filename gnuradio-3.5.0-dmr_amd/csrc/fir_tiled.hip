@@ -269,7 +269,10 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             if (part >= 0 && i / PER != part) continue;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + i * (LANE_BYTES * TILED_THREADS), 0, 0);
+            // rounds past the end of the tile (short filters, small decimation) are pointed
+            // out of range: zeros, no memory traffic, still no branch around a load
+            const int vo = (i * 2 * TILED_THREADS - 1 < Lu) ? voff + i * (LANE_BYTES * TILED_THREADS) : 0x7ffff000;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
             const f32x4 f = __builtin_bit_cast(f32x4, v);
             pf[i] = make_float4(f[0], f[1], f[2], f[3]);
         }
@@ -311,7 +314,7 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
             } else if (i < FULL) {
                 dst0[SLOT_STEP * i] = e0;
                 dst1[SLOT_STEP * i] = e1;
-            } else {
+            } else if (i * 2 * TILED_THREADS - 1 < Lu) {     // wave-uniform: the round exists
                 if (u < Lu) dst0[SLOT_STEP * i] = e0;
                 if (u + 1 < Lu) dst1[SLOT_STEP * i] = e1;
             }
@@ -647,6 +650,9 @@ int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiled
         if (e) sscanf(e, "%d,%d", &skew_mode, &skew_sleeps);
     }
     a.skew_mode = skew_mode; a.skew_sleeps = skew_sleeps;
+    // the tile queue's counter round trip hides under the MAC loop of a long filter only;
+    // short filters keep the static split
+    if (a.Tq * decim < 128) a.sched = nullptr;
     switch (decim) {
     case 1: return launch_tiled_d<1>(ctaps, premix, epi, a, st);
     case 2: return launch_tiled_d<2>(ctaps, premix, epi, a, st);

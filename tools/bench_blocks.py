@@ -2,6 +2,7 @@
 at its BASELINE size on one GPU, device-resident, as algorithmic GB/s against the
 8 TB/s HBM peak.  usage: python tools/bench_blocks.py"""
 import json
+import time
 import os
 import sys
 
@@ -19,7 +20,13 @@ st = torch.cuda.Stream(device=dev)
 PEAK = 8000.0
 
 
-def timeit(fn, reps=20, warm=3):
+def timeit(fn, reps=50, warm=3, ramp_s=0.3):
+    # an idle MI355X needs tens of ms of load before its shader clock reaches steady state
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < ramp_s:
+        for _ in range(10):
+            fn()
+        st.synchronize()
     for _ in range(warm):
         fn()
     st.synchronize()
@@ -41,23 +48,23 @@ def report(name, ms, items, bytes_per_item, unit="Msamples/s"):
 rng = np.random.default_rng(0)
 
 # cfg1: fir_filter_ccf 64 taps, D=1, 1 M samples (and 16 M to get out of launch-latency land)
-for n in (1_000_000, 16_000_000):
+for n in (1_000_000, 16_000_000, 128_000_000):
     x = torch.randn((n + 64, 2), device=dev)
     y = torch.empty((n, 2), device=dev)
     blk = g.fir_filter_ccf(1, wl.lowpass_taps(64, 0.1, 1.0))
     report("fir_filter_ccf 64t D=1 n=%d" % n, timeit(lambda: blk.work_device(n, x, y, st)), n, 16)
 
 # published-baseline shape (mp-sched, fir_filter_fff 256 taps, decimation 1)
-n = 16_000_000
+n = 128_000_000
 xf = torch.randn(n + 256, device=dev)
 yf = torch.empty(n, device=dev)
 blk = g.fir_filter_fff(1, wl.lowpass_taps(256, 0.1, 1.0))
-report("fir_filter_fff 256t D=1 FAST (tiled kernel, float-pair mode)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=5), n, 8)
+report("fir_filter_fff 256t D=1 FAST (tiled kernel, float-pair mode)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=20), n, 8)
 blk.set_mode(g.MODE_GENERIC)
-report("fir_filter_fff 256t D=1 GENERIC (bit-exact order)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=5), n, 8)
+report("fir_filter_fff 256t D=1 GENERIC (bit-exact order)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=20), n, 8)
 
 # unfused xlating (10 B / input sample) and quad_demod (12 B / item)
-n = 10_000_000
+n = 160_000_000
 c = wl.CFG2
 x = torch.randn((n + 256, 2), device=dev)
 y = torch.empty((n // 4, 2), device=dev)
