@@ -12,19 +12,32 @@ namespace grhip {
 // Mueller & Mueller clock recovery
 //   gr-digital/lib/digital_clock_recovery_mm_ff.cc:104-139
 //   filter/gri_mmse_fir_interpolator.cc:61-71 (8-tap gr_fir_fff, 129 phases)
-// The loop is serial and data dependent: one wavefront per stream.
-// All 64 lanes stage the next MM_CH input floats into LDS with coalesced loads;
-// lane 0 then walks the symbols inside that window out of LDS (interpolator
-// taps also in LDS), so the dependent chain never waits on HBM.  Throughput
-// comes from running many independent streams (one workgroup each).
-// Every float operation below is a single unfused IEEE op in the reference's
-// order: bit-exact.
+// The loop is serial and data dependent: one wavefront per stream, and a
+// lone wavefront issues one instruction every ~5 cycles, so the cost of a symbol is the
+// NUMBER of instructions between two symbols.  The kernel keeps that number small:
+//  * all 64 lanes stage the next MM_CH input floats into LDS with coalesced loads;
+//  * the loop state (mu, omega, last sample) is computed redundantly by every lane, the
+//    sample position and output count are wave-uniform scalars: no exec-mask juggling;
+//  * lanes 0..7 each form ONE tap product of the 8-tap interpolator (two LDS reads per
+//    symbol instead of sixteen) and DPP row shifts add them up in the reference's order,
+//    gr_fir_fff_generic::filter with N_UNROLL = 4: acc_j = (0 + p_j) + p_{j+4},
+//    out = ((acc_0 + acc_1) + acc_2) + acc_3;
+//  * outputs are collected in LDS and written out coalesced once per window.
+// Every float operation is a single unfused IEEE op in the reference's order: bit-exact.
 // ===========================================================================
 constexpr int MM_CH = 4096;
 constexpr int MM_NTAPS = 8;
 constexpr int MM_NSTEPS = 128;
+constexpr int MM_OUT = 1024;        // outputs buffered per window (a window of 4096 inputs yields ~MM_CH/omega)
 
-__device__ __forceinline__ float mm_slice(float x) { return x < 0 ? -1.0f : 1.0f; }
+__device__ __forceinline__ float mm_slice_mul(float s, float v) { return s < 0 ? -v : v; }     // slice(s) * v, slice = -1 / +1
+
+// lane i <- lane i+n of its row of 16 (zero beyond the row)
+template <int N>
+__device__ __forceinline__ float row_shl(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
 
 __global__ void __launch_bounds__(64)
 mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, const float *__restrict__ in,
@@ -33,7 +46,7 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
 {
     __shared__ float s_in[MM_CH];
     __shared__ float s_taps[MM_NTAPS * (MM_NSTEPS + 1)];
-    __shared__ int s_ctl[4];
+    __shared__ float s_out[MM_OUT];
 
     const int s = blockIdx.x, lane = threadIdx.x;
     const float *__restrict__ x = in + (long long)s * in_stride;
@@ -41,62 +54,56 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
 
     for (int i = lane; i < MM_NTAPS * (MM_NSTEPS + 1); i += 64) s_taps[i] = mmse_rev[i];
 
-    MMState st = state[s];
-    int ii = 0, oo = 0;
-    const int ni = ninput_items - MM_NTAPS;          // .cc:113
-    int done = !(oo < noutput_items && ii < ni);
+    const MMState st = state[s];
+    float mu = st.mu, omega = st.omega, last = st.last_sample;          // identical in every lane
+    const float omega_mid = st.omega_mid, gain_omega = st.gain_omega, gain_mu = st.gain_mu;
+    const float rel = st.omega_relative_limit;
+    int ii = 0, oo = 0;                               // wave-uniform (kept in SGPRs)
+    const int ni = ninput_items - MM_NTAPS;           // .cc:113
+    const int k = lane & 7;                           // this lane's tap of the interpolator
+    const float *tapcol = &s_taps[k * (MM_NSTEPS + 1)];
+    bool done = !(oo < noutput_items && ii < ni);
 
     while (!done) {
-        const int base = ii;
+        const int base = ii, obase = oo;
         for (int i = lane; i < MM_CH; i += 64) {
             long long g = (long long)base + i;
             s_in[i] = (g >= 0 && g < ninput_items) ? x[g] : 0.f;
         }
         __syncthreads();
-        if (lane == 0) {
-            const int lim = base + MM_CH - MM_NTAPS;
-            float mu = st.mu, omega = st.omega, last = st.last_sample;
-            const float omega_mid = st.omega_mid, gain_omega = st.gain_omega, gain_mu = st.gain_mu;
-            const float rel = st.omega_relative_limit;
-            while (oo < noutput_items && ii < ni && ii <= lim && ii >= base) {
-                // interpolate(&in[ii], d_mu): imu = (int) rint(mu * NSTEPS)
-                int imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
-                imu = imu < 0 ? 0 : (imu > MM_NSTEPS ? MM_NSTEPS : imu);
-                const float *xw = &s_in[ii - base];
-                const float *tp = &s_taps[imu];
-                // gr_fir_fff_generic::filter, ntaps = 8, N_UNROLL = 4
-                float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-                acc0 += tp[0 * (MM_NSTEPS + 1)] * xw[0];
-                acc1 += tp[1 * (MM_NSTEPS + 1)] * xw[1];
-                acc2 += tp[2 * (MM_NSTEPS + 1)] * xw[2];
-                acc3 += tp[3 * (MM_NSTEPS + 1)] * xw[3];
-                acc0 += tp[4 * (MM_NSTEPS + 1)] * xw[4];
-                acc1 += tp[5 * (MM_NSTEPS + 1)] * xw[5];
-                acc2 += tp[6 * (MM_NSTEPS + 1)] * xw[6];
-                acc3 += tp[7 * (MM_NSTEPS + 1)] * xw[7];
-                const float o = (acc0 + acc1 + acc2 + acc3);
-                y[oo] = o;
-                const float mm_val = mm_slice(last) * o - mm_slice(o) * last;     // .cc:120
-                last = o;
-                omega = omega + gain_omega * mm_val;                              // .cc:123
-                omega = omega_mid + branchless_clip(omega - omega_mid, rel);      // .cc:124
-                mu = mu + omega + gain_mu * mm_val;                               // .cc:125
-                const float fl = __builtin_floorf(mu);
-                ii += (int)fl;                                                    // .cc:127
-                mu = mu - fl;                                                     // .cc:128
-                oo++;
-            }
-            st.mu = mu; st.omega = omega; st.last_sample = last;
-            int d = !(oo < noutput_items && ii < ni);
-            if (ii < 0) d = 1;     // the reference would read before its buffer here
-            s_ctl[0] = ii; s_ctl[1] = oo; s_ctl[2] = d;
+        const int lim = base + MM_CH - MM_NTAPS;
+        const float *xk = &s_in[k - base];
+        while (oo < noutput_items && ii < ni && ii <= lim && ii >= base && oo - obase < MM_OUT) {
+            // interpolate(&in[ii], d_mu): imu = (int) rint(mu * NSTEPS)
+            int imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
+            imu = imu < 0 ? 0 : (imu > MM_NSTEPS ? MM_NSTEPS : imu);
+            const float p = tapcol[imu] * xk[ii];                         // lanes 0..7: tap k times sample k
+            const float acc = (0.0f + p) + row_shl<4>(p);                 // lanes 0..3: acc_j
+            float o = acc + row_shl<1>(acc);
+            o = o + row_shl<2>(acc);
+            o = o + row_shl<3>(acc);
+            o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o), 0));
+            s_out[oo - obase] = o;
+            const float mm_val = mm_slice_mul(last, o) - mm_slice_mul(o, last);   // .cc:120
+            last = o;
+            omega = omega + gain_omega * mm_val;                              // .cc:123
+            omega = omega_mid + branchless_clip(omega - omega_mid, rel);      // .cc:124
+            mu = mu + omega + gain_mu * mm_val;                               // .cc:125
+            const float fl = __builtin_floorf(mu);
+            ii = __builtin_amdgcn_readfirstlane(ii + (int)fl);                // .cc:127
+            mu = mu - fl;                                                     // .cc:128
+            oo++;
         }
         __syncthreads();
-        ii = s_ctl[0]; oo = s_ctl[1]; done = s_ctl[2];
+        for (int i = lane; i < oo - obase; i += 64) y[obase + i] = s_out[i];
+        done = !(oo < noutput_items && ii < ni);
+        if (ii < 0) done = true;     // the reference would read before its buffer here
         __syncthreads();
     }
     if (lane == 0) {
-        state[s] = st;
+        MMState so = st;
+        so.mu = mu; so.omega = omega; so.last_sample = last;
+        state[s] = so;
         counts[2 * s + 0] = oo;
         counts[2 * s + 1] = ii;          // consume_each(ii)
     }

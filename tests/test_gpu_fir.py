@@ -249,6 +249,39 @@ def test_fused_xlating_demod_cfg2(gpu, po, wl):
     assert ok, worst
 
 
+@pytest.mark.parametrize("stride_pad,n", [(0, 2_000_000), (63, 1_900_001)])
+def test_run_captures_batched_vs_oracle(gpu, po, wl, stride_pad, n):
+    """one batched launch over 5 captures: more tiles than the static share of the
+    persistent grid (the tile queue hands out the rest), odd stream stride (the streams'
+    16-byte alignment parity alternates, so the pre-mix phasors are rebuilt between
+    tiles), capture length not a multiple of the decimation or the tile"""
+    import torch
+    c = wl.CFG2
+    S = 5
+    proto = wl.cfg2_proto_taps()
+    xs = [wl.fsk4_capture(n, stream_id=70 + s) for s in range(S)]
+    dev = torch.device("cuda", 0)
+    stride = n + stride_pad
+    d_in = torch.zeros((S * stride + 8, 2), dtype=torch.float32, device=dev)
+    for s in range(S):
+        d_in[s * stride: s * stride + n] = torch.from_numpy(xs[s].view(np.float32).reshape(-1, 2))
+    nout = n // c["decim"]
+    ostride = ((nout + 3) // 4) * 4
+    d_out = torch.zeros((S, ostride), dtype=torch.float32, device=dev)
+    blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
+    st = torch.cuda.Stream(device=dev)
+    for rep in range(2):            # second launch: the queue re-armed itself
+        d_out.zero_()
+        blk.run_captures_device(S, n, d_in, stride, d_out, ostride, st)
+        st.synchronize()
+        got = d_out.cpu().numpy()
+        for s in range(S):
+            ref = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"],
+                                         xs[s][: nout * c["decim"]])
+            ok, worst = demod_close(got[s, :nout], ref)
+            assert ok, (rep, s, worst)
+
+
 def test_fused_xlating_demod_mode_switch_mid_stream(gpu, po, wl):
     """FAST and GENERIC keep the demodulator's one-sample carry in different frames
     (fir_kernels.h, EPI_DEMOD); switching between work() calls converts it"""
