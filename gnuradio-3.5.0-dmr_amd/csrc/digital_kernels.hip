@@ -157,21 +157,12 @@ int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipSt
 constexpr int CORR_TB = 8192;     // outputs per workgroup (4 rounds of 8 per lane)
 constexpr int CORR_WORDS = CORR_TB / 64 + 2;
 
-__device__ __forceinline__ unsigned long long corr_word(const unsigned long long *P, long long w,
-                                                        long long wlo, unsigned long long data_reg)
-{
-    // packed word w (stream bits 64w .. 64w+63, first bit at the MSB)
-    if (w == -1) return data_reg;
-    if (w < -1) return 0ull;
-    return P[w - wlo];
-}
-
 __global__ void __launch_bounds__(256)
 corr_kernel(CorrParams p, const CorrState *__restrict__ state_in, const unsigned char *__restrict__ in_bytes,
             const float *__restrict__ in_soft, long long in_stride, unsigned char *__restrict__ out,
             long long out_stride, long long n_arg, const int *__restrict__ n_ptr, int n_ptr_stride)
 {
-    __shared__ unsigned long long P[CORR_WORDS];
+    __shared__ unsigned long long P[CORR_WORDS + 1];    // + one word of slack for the unconditional look-ahead read
     const int s = blockIdx.y, t = threadIdx.x;
     long long n = n_arg;
     if (n_ptr) { long long m = n_ptr[(long long)s * n_ptr_stride]; n = m < n ? m : n; }
@@ -180,6 +171,7 @@ corr_kernel(CorrParams p, const CorrState *__restrict__ state_in, const unsigned
     const unsigned char *__restrict__ xb = in_bytes ? in_bytes + (long long)s * in_stride : nullptr;
     const float *__restrict__ xf = in_soft ? in_soft + (long long)s * in_stride : nullptr;
     const CorrState st = state_in[s];
+    if (t == 0) P[CORR_WORDS] = 0;      // slack word (read by the look-ahead, its bits are never used)
 
     // words i0/64 - 2 .. i0/64 + CORR_TB/64 - 1, first item of a word at its MSB.
     // Wide path: a lane takes 16 input bytes (or 8 floats) with 16-byte loads, squeezes
@@ -248,40 +240,55 @@ corr_kernel(CorrParams p, const CorrState *__restrict__ state_in, const unsigned
     }
     __syncthreads();
 
+    // words before the call: w = -1 is the shift register carried in, older ones are zero
+    // (the ballot path above has packed zeros there; only the first tile of a stream has them)
+    if (i0 == 0) {
+        if (t == 0) P[1] = st.data_reg;
+        __syncthreads();
+    }
+    const unsigned chi = (unsigned)(p.access_code >> 32), clo = (unsigned)p.access_code;
+    const unsigned mhi = (unsigned)(p.mask >> 32), mlo = (unsigned)p.mask;
+
+    // A lane emits 8 consecutive outputs per round.  Their bit 0 is one byte of one packed
+    // word; their flags come from ONE 64-bit window that slides by a bit per output
+    // (two 32-bit halves: a funnel shift and a shift-or), instead of re-assembling the
+    // window from LDS for every output.
     unsigned char *__restrict__ y = out + (long long)s * out_stride;
     for (int rnd = 0; rnd < CORR_TB / 2048; ++rnd) {
-        unsigned long long packed = 0;
         const long long o0 = i0 + 2048ll * rnd + 8 * t;
         if (o0 >= n) break;
+        // bit 0 of outputs o0 .. o0+7: stream bits o0-64 .. o0-57 (same word, byte aligned)
+        const long long b0 = o0 - 64;
+        const unsigned byte0 = (unsigned)(P[(b0 >> 6) - wlo] >> (56 - (int)(b0 & 63))) & 0xFFu;
+        // window of output o0: stream bits k0-64 .. k0-1, k0 = o0 - len; then bits k0 .. k0+6 slide in
+        const long long k0 = o0 - (long long)p.len;
+        const long long wk = k0 >> 6;                          // floor division (arithmetic shift)
+        const int rk = (int)(k0 & 63);
+        const unsigned long long hi = P[wk - 1 - wlo], lo = P[wk - wlo], nx = P[wk + 1 - wlo];
+        const unsigned long long W0 = rk ? (hi << rk) | (lo >> (64 - rk)) : hi;
+        const unsigned nb = (unsigned)((rk ? (lo << rk) | (nx >> (64 - rk)) : lo) >> 56);
+        unsigned whi = (unsigned)(W0 >> 32), wlo32 = (unsigned)W0;
+        unsigned out_lo = 0, out_hi = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const long long i = o0 + j;
-            unsigned o = 0;
-            if (i < n) {
-                // bit 0: stream bit i-64
-                long long b = i - 64;
-                long long w = b >> 6;                          // floor division (arithmetic shift)
-                int r = (int)(b & 63);
-                o |= (unsigned)((corr_word(P, w, wlo, st.data_reg) >> (63 - r)) & 1ull);
-                // bit 1: flags already in flight at call start
-                if (i < 64) o |= (unsigned)((st.flag_reg >> (63 - i)) & 1ull) << 1;
-                // bit 1: flag computed len items ago
-                long long k = i - (long long)p.len;
-                if (k >= 0 && p.len > 0) {
-                    long long wk = k >> 6;
-                    int rk = (int)(k & 63);
-                    unsigned long long hi = corr_word(P, wk - 1, wlo, st.data_reg);
-                    unsigned long long W = hi;
-                    if (rk) W = (hi << rk) | (corr_word(P, wk, wlo, st.data_reg) >> (64 - rk));
-                    unsigned nwrong = (unsigned)__popcll((W ^ p.access_code) & p.mask);
-                    if (nwrong <= p.threshold) o |= 2u;
-                }
+            unsigned o = (byte0 >> (7 - j)) & 1u;
+            const unsigned nwrong = (unsigned)__popc((whi ^ chi) & mhi) + (unsigned)__popc((wlo32 ^ clo) & mlo);
+            if (nwrong <= p.threshold && k0 + j >= 0 && p.len > 0) o |= 2u;
+            whi = (whi << 1) | (wlo32 >> 31);
+            wlo32 = (wlo32 << 1) | ((nb >> (7 - j)) & 1u);
+            if (j < 4) out_lo |= o << (8 * j); else out_hi |= o << (8 * (j - 4));
+        }
+        if (o0 < 64) {          // flags already in flight at call start
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned f = (unsigned)((st.flag_reg >> (63 - (int)(o0 + j))) & 1ull) << 1;
+                if (j < 4) out_lo |= f << (8 * j); else out_hi |= f << (8 * (j - 4));
             }
-            packed |= (unsigned long long)o << (8 * j);
         }
         if (o0 + 8 <= n && ((((uintptr_t)(y + o0)) & 7) == 0)) {
-            *reinterpret_cast<unsigned long long *>(y + o0) = packed;
+            *reinterpret_cast<uint2 *>(y + o0) = make_uint2(out_lo, out_hi);
         } else {
+            const unsigned long long packed = ((unsigned long long)out_hi << 32) | out_lo;
             for (int j = 0; j < 8; ++j)
                 if (o0 + j < n) y[o0 + j] = (unsigned char)(packed >> (8 * j));
         }
