@@ -638,6 +638,12 @@ int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiled
 {
     if (a_in.n_out <= 0 || n_streams <= 0) return GRHIP_OK;
     if (!tiled_supported(decim, a_in.Tq)) return fail(GRHIP_EINVAL, "tiled FIR: unsupported shape");
+    // streams are addressed with 32-bit byte offsets inside a buffer descriptor
+    {
+        const long long item = a_in.fpair ? 4 : 8;
+        if ((a_in.n_in - a_in.n_lo) * item >= (1ll << 31) - (1ll << 20))
+            return fail(GRHIP_EINVAL, "tiled FIR: more than 2 GiB of input per stream in one call; call work() in pieces");
+    }
     FirTiledArgs a = a_in;
     a.n_streams = n_streams;
     static int ablate = -1;
