@@ -118,11 +118,143 @@ fft_kernel(int N, int shift, const float *__restrict__ window, const float2 *__r
     }
 }
 
+// ---------------------------------------------------------------------------
+// N = 4096 (config 3): three radix-16 Stockham passes, one butterfly per lane and pass.
+// The 16 points of a butterfly live in registers, so the first pass reads HBM directly
+// (coalesced: point q of lane t is x[t + 256 q]) and the last writes HBM directly; LDS
+// only carries the two exchanges in between (one padded 34 KB buffer, conflict-free for
+// both the stride-16 writes and the stride-1 reads), against six LDS round trips and six
+// barriers of the radix-4 kernel.  A radix-16 butterfly is 4 x radix-4, seven constant
+// twiddles, 4 x radix-4.  External twiddles come from the same double-precision table.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// DFT of 4 points in place (forward: W4 = -i)
+template <bool FWD>
+__device__ __forceinline__ void radix4(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+    const float2 s0 = c_add(a, c), d0 = c_sub(a, c), s1 = c_add(b, d), d1 = c_sub(b, d);
+    const float2 r = FWD ? make_float2(d1.y, -d1.x) : make_float2(-d1.y, d1.x);     // -/+ i (b - d)
+    a = c_add(s0, s1);
+    b = c_add(d0, r);
+    c = c_sub(s0, s1);
+    d = c_sub(d0, r);
+}
+
+// v[m] <- sum_n v[n] W16^{nm}, n = c + 4d, m = r + 4s
+template <bool FWD>
+__device__ __forceinline__ void dft16(float2 (&v)[16])
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) radix4<FWD>(v[c], v[c + 4], v[c + 8], v[c + 12]);    // v[c + 4r] = a[c][r]
+    const float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+    const float sg = FWD ? -1.f : 1.f;
+    const float2 w1 = make_float2(C1, sg * S1), w2 = make_float2(H, sg * H), w3 = make_float2(S1, sg * C1);
+    const float2 w6 = make_float2(-H, sg * H), w9 = make_float2(-C1, -sg * S1);
+    // a[c][r] *= W16^{c r}
+    v[1 + 4] = cmul_fma(v[1 + 4], w1);
+    v[1 + 8] = cmul_fma(v[1 + 8], w2);
+    v[1 + 12] = cmul_fma(v[1 + 12], w3);
+    v[2 + 4] = cmul_fma(v[2 + 4], w2);
+    v[2 + 8] = FWD ? make_float2(v[2 + 8].y, -v[2 + 8].x) : make_float2(-v[2 + 8].y, v[2 + 8].x);   // W16^4 = -/+ i
+    v[2 + 12] = cmul_fma(v[2 + 12], w6);
+    v[3 + 4] = cmul_fma(v[3 + 4], w3);
+    v[3 + 8] = cmul_fma(v[3 + 8], w6);
+    v[3 + 12] = cmul_fma(v[3 + 12], w9);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) radix4<FWD>(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);  // v[4r + s] = X[r + 4s]
+    // un-permute: X[m], m = r + 4s, sits at 4r + s
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s2 = r + 1; s2 < 4; ++s2) {
+            const float2 tmp = v[4 * r + s2];
+            v[4 * r + s2] = v[4 * s2 + r];
+            v[4 * s2 + r] = tmp;
+        }
+}
+
+template <bool FWD>
+__global__ void __launch_bounds__(256, 4)
+fft4096_kernel(int shift, const float *__restrict__ window, const float2 *__restrict__ twiddle,
+               const float2 *__restrict__ in, float2 *__restrict__ out)
+{
+    constexpr int N = 4096;
+    __shared__ float2 S[N + N / 16];
+    auto pad = [](int i) { return i + (i >> 4); };
+    const int t = threadIdx.x;
+    const float2 *__restrict__ x = in + (long long)blockIdx.x * N;
+    float2 *__restrict__ y = out + (long long)blockIdx.x * N;
+    float2 v[16];
+
+    // ---- pass 1 (p = 1): points straight from HBM (gr_fft_vcc_fftw.cc:68-83)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = t + 256 * q;
+        if (window) {
+            const float2 a = x[i];
+            const float w = window[i];
+            v[q] = make_float2(a.x * w, a.y * w);
+        } else if (!FWD && shift) {
+            v[q] = x[(i + N / 2) & (N - 1)];          // dst[k] = in[(k + N/2) mod N]
+        } else {
+            v[q] = x[i];
+        }
+    }
+    dft16<FWD>(v);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) S[pad(16 * t + m)] = v[m];
+    __syncthreads();
+
+    // ---- pass 2 (p = 16): twiddle W_256^{k q} = W_N^{16 k q}
+    {
+        const int k = t & 15;
+        float2 w[16];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) w[q] = tw<FWD>(twiddle, 16 * k * q);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = S[pad(t + 256 * q)];
+        __syncthreads();                               // every lane has read before anyone writes
+#pragma unroll
+        for (int q = 1; q < 16; ++q) v[q] = cmul_fma(v[q], w[q]);
+        dft16<FWD>(v);
+        const int j = (t - k) * 16 + k;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) S[pad(j + 16 * m)] = v[m];
+        __syncthreads();
+    }
+
+    // ---- pass 3 (p = 256): twiddle W_N^{t q}; results straight to HBM (gr_fft_vcc_fftw.cc:89-96)
+    {
+        float2 w[16];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) w[q] = tw<FWD>(twiddle, t * q);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = S[pad(t + 256 * q)];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) v[q] = cmul_fma(v[q], w[q]);
+        dft16<FWD>(v);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int idx = t + 256 * m;
+            // forward + shift: out[k] = fft[(k + N/2) mod N]
+            y[(FWD && shift) ? ((idx + N / 2) & (N - 1)) : idx] = v[m];
+        }
+    }
+}
+
 int launch_fft(int N, int forward, int shift, const float *window, const float2 *twiddle, const float2 *in,
                float2 *out, long long nvec, hipStream_t st)
 {
     if (nvec <= 0) return GRHIP_OK;
     if (!fft_size_supported(N)) return fail(GRHIP_EINVAL, "fft size %d not supported on device", N);
+    if (N == 4096) {
+        if (forward) hipLaunchKernelGGL(fft4096_kernel<true>, dim3((unsigned)nvec), dim3(256), 0, st, shift, window, twiddle, in, out);
+        else hipLaunchKernelGGL(fft4096_kernel<false>, dim3((unsigned)nvec), dim3(256), 0, st, shift, window, twiddle, in, out);
+        GRHIP_HIP(hipGetLastError());
+        return GRHIP_OK;
+    }
     size_t lds = (size_t)N * 2 * sizeof(float2);
     static size_t cfg_f = 0, cfg_b = 0;
     if (forward) {

@@ -44,9 +44,9 @@ def test_fft_sizes_vs_oracle(gpu, po, N, forward):
 
 @pytest.mark.parametrize("forward,shift,win", [(True, True, False), (False, True, False), (True, False, True),
                                                (False, True, True), (True, True, True)])
-def test_fft_window_and_shift(gpu, po, forward, shift, win):
+@pytest.mark.parametrize("N,nvec", [(256, 7), (4096, 3)])     # 4096: the radix-16 kernel
+def test_fft_window_and_shift(gpu, po, forward, shift, win, N, nvec):
     rng = np.random.default_rng(5)
-    N, nvec = 256, 7
     x = _rc(rng, N * nvec)
     w = np.hamming(N).astype(np.float32) if win else None
     ref = po.fft_vcc(N, forward, w, shift, x)
