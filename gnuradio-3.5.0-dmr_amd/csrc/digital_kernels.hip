@@ -77,14 +77,22 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
             // interpolate(&in[ii], d_mu): imu = (int) rint(mu * NSTEPS)
             int imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
             imu = imu < 0 ? 0 : (imu > MM_NSTEPS ? MM_NSTEPS : imu);
-            const float p = tapcol[imu] * xk[ii];                         // lanes 0..7: tap k times sample k
-            const float acc = (0.0f + p) + row_shl<4>(p);                 // lanes 0..3: acc_j
+            // lanes 0..7: (0 + tap k * sample k) -- the fma rounds the product once and adds an
+            // exact zero, i.e. the reference's `acc = 0; acc += t*x` including the sign of a
+            // zero product; using it for the upper partner too changes nothing (a + -0 == a + +0
+            // unless a is a zero, and then both give +0)
+            const float p = __builtin_fmaf(tapcol[imu], xk[ii], 0.0f);
+            const float acc = p + row_shl<4>(p);                          // lanes 0..3: acc_j
             float o = acc + row_shl<1>(acc);
             o = o + row_shl<2>(acc);
             o = o + row_shl<3>(acc);
             o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o), 0));
             s_out[oo - obase] = o;
-            const float mm_val = mm_slice_mul(last, o) - mm_slice_mul(o, last);   // .cc:120
+            // .cc:120  slice(last)*o - slice(o)*last; slice(o) = +-1 is the sign of o glued onto
+            // 1.0 (o is never -0: it is a sum that started from +0), and since slice(o)*last is
+            // exact the fma below rounds exactly like the reference's subtraction
+            const float so = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, o) & 0x80000000u) | 0x3f800000u);
+            const float mm_val = __builtin_fmaf(-so, last, mm_slice_mul(last, o));
             last = o;
             omega = omega + gain_omega * mm_val;                              // .cc:123
             omega = omega_mid + branchless_clip(omega - omega_mid, rel);      // .cc:124
