@@ -367,12 +367,15 @@ template <int M>
 __global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a)
 {
     constexpr int R = 8, TT = 64 * R;                  // output vectors per tile
+    constexpr int LOGM = M == 1 ? 0 : M == 2 ? 1 : M == 4 ? 2 : M == 8 ? 3 : 4;
+    static_assert((1 << LOGM) == M, "M must be a power of two <= 16");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tpfp = (a.tpf + R - 1) / R * R;          // taps padded to a multiple of R (zeros)
     const int XS = (TT + tpfp + R) + (TT + tpfp + R) / R + 1;   // slots per stream, padded
     const int SS = TT + TT / R + 1;                    // slots per IFFT input row, padded
     float2 *xs = (float2 *)smem;                       // [M][XS]
-    float2 *sl = xs + (size_t)M * XS;                  // [M][SS]
+    float2 *sl = xs;                                   // [M][SS], SS < XS: reuses the sample buffer once every
+                                                       // wave is done with its FIR (40 KB instead of 77 KB: 3 workgroups per CU)
     const int t = threadIdx.x, j = t >> 6, ln = t & 63;
     const long long t0 = (long long)blockIdx.x * TT;
     const pfb_cfloat_p taps = (pfb_cfloat_p)(a.ftaps) + (size_t)(M - 1 - j) * a.tpf;
@@ -416,6 +419,7 @@ __global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a)
         }
     }
     // ---- to IFFT slot M-1-j, transposed: sl[slot][t_local]
+    __syncthreads();                                   // sl aliases xs
     {
         float2 *row = sl + (size_t)(M - 1 - j) * SS + ln * R + ln;
 #pragma unroll
@@ -433,11 +437,15 @@ __global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a)
         for (int s = 0; s < M; ++s) {
             int rv = 0;
 #pragma unroll
-            for (int b = 1, c = M >> 1; b < M; b <<= 1, c >>= 1) if (s & b) rv |= c;
+            for (int bit = 0; bit < LOGM; ++bit)
+                if (s & (1 << bit)) rv |= (M >> 1) >> bit;
             v[rv] = sl[(size_t)s * SS + tl + (tl >> 3)];
         }
+        // (canonical loop bounds everywhere: anything the compiler cannot unroll turns v[] into
+        // a scratch array)
 #pragma unroll
-        for (int len = 2; len <= M; len <<= 1) {
+        for (int stg = 0; stg < LOGM; ++stg) {
+            const int len = 2 << stg;
             const int half = len >> 1, step = M / len;
 #pragma unroll
             for (int s0 = 0; s0 < M; s0 += len) {
@@ -470,7 +478,8 @@ static int launch_pfb_os1(const PfbArgs &a, hipStream_t st)
     const int tpfp = (a.tpf + R - 1) / R * R;
     const int XS = (TT + tpfp + R) + (TT + tpfp + R) / R + 1;
     const int SS = TT + TT / R + 1;
-    size_t lds = ((size_t)M * XS + (size_t)M * SS) * sizeof(float2);
+    (void)SS;
+    size_t lds = (size_t)M * XS * sizeof(float2);
     if (lds > 150 * 1024) return -1;
     static size_t cfg = 0;
     if (lds > 48 * 1024 && lds > cfg) {
