@@ -546,6 +546,9 @@ __global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kern
         __syncthreads();        // xs is rewritten by the next tile
         STAMP(6);
         if (a.sched) nn = sched_slot[0];
+        // (wave-uniform by construction; saying so keeps the stream's buffer descriptor in SGPRs --
+        // otherwise every load is wrapped in a waterfall loop)
+        nn = (unsigned)__builtin_amdgcn_readfirstlane((int)nn);
         cur = nxt; nxt = nn;
         s = s_nxt; bidx = b_nxt;
     }
