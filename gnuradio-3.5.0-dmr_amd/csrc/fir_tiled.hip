@@ -57,7 +57,15 @@ static_assert(TILED_R == 8 || TILED_R == 4, "R must be 4 or 8");
 constexpr int TILED_THREADS = GRHIP_TILED_THREADS;
 constexpr int TILED_NT = TILED_THREADS * TILED_R;
 constexpr int TILED_WG_PER_CU = (TILED_R == 8 ? 2 : 3) * 256 / TILED_THREADS;
-constexpr int TILED_NI = TILED_R == 8 ? 18 : 11;       // 16-byte loads per lane per tile (upper bound)
+constexpr int TILED_NI = TILED_R == 8 ? 18 : 11;       // 16-byte loads per lane per tile at decimation 4 (upper bound)
+// rounds of loads a tile can need at decimation D: (NT + Tq) D / 512 with up to 1024 taps
+// plain decimation-1 filters stage 6 rounds instead of 18: their registers fit four workgroups
+// per CU (the LDS tile of a short filter is small), which hides more of the per-tile latencies
+__host__ __device__ constexpr int tiled_wg_per_cu(int D, bool premix, int epi)
+{
+    return (D == 1 && !premix && epi == 0) ? 2 * TILED_WG_PER_CU : TILED_WG_PER_CU;
+}
+__host__ __device__ constexpr int tiled_ni(int D) { return D >= 4 ? TILED_NI : D == 2 ? 10 : 6; }
 constexpr int TILED_LDS_LIMIT = (160 * 1024) / TILED_WG_PER_CU - 256;
 
 int tiled_R() { return TILED_R; }
@@ -101,7 +109,7 @@ bool tiled_supported(int decim, int Tq)
 {
     if (!(decim == 1 || decim == 2 || decim == 4)) return false;
     if (Tq <= 0 || (Tq % TILED_R) != 0) return false;
-    if ((TILED_NT + Tq) * decim > TILED_NI * 2 * TILED_THREADS) return false;
+    if ((TILED_NT + Tq) * decim > tiled_ni(decim) * 2 * TILED_THREADS) return false;
     return tiled_lds_bytes(decim, Tq) <= (size_t)TILED_LDS_LIMIT;
 }
 
@@ -144,10 +152,10 @@ __device__ __forceinline__ float wave_sum(float x)
 // never materialised: each lane loads 16 bytes (4 floats) at an 8-byte lane stride and
 // forms its two items while staging; the outputs land in a plain float array.
 template <int D, bool CTAPS, bool PREMIX, int EPI, int FP = 0>
-__global__ void __launch_bounds__(TILED_THREADS, TILED_WG_PER_CU) fir_tiled_kernel(const FirTiledArgs a)
+__global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)) fir_tiled_kernel(const FirTiledArgs a)
 {
     static_assert(FP == 0 || (D == 2 * FP && !CTAPS && !PREMIX && EPI == EPI_NONE), "float-pair mode");
-    constexpr int R = TILED_R, LOGR = TILED_LOGR, NT = TILED_NT, NI = TILED_NI;
+    constexpr int R = TILED_R, LOGR = TILED_LOGR, NT = TILED_NT, NI = tiled_ni(D);
     constexpr int LOGD = ilog2(D);
     constexpr int TW = CTAPS ? 2 : 1;               // floats per tap
     constexpr bool ROT = EPI == EPI_ROTATE || EPI == EPI_ROTATE_DEMOD;     // rotator table multiply
@@ -592,8 +600,11 @@ static int launch_tiled_inst(const FirTiledArgs &a, hipStream_t st)
     constexpr int NEW_PER_TILE = EPI == EPI_DEMOD ? TILED_NT - TILED_R * (TILED_THREADS / 64) : TILED_NT;
     const long long tiles = ((a.n_out + NEW_PER_TILE - 1) / NEW_PER_TILE) * a.n_streams;
     static int wg_per_cu = 0;
-    if (!wg_per_cu) { const char *e = getenv("GRHIP_WGPCU"); wg_per_cu = e ? atoi(e) : TILED_WG_PER_CU; }   // tuning knob
-    long long grid = (long long)wg_per_cu * g_num_cus;   // persistent workgroups
+    if (!wg_per_cu) { const char *e = getenv("GRHIP_WGPCU"); wg_per_cu = e ? atoi(e) : -1; }   // tuning knob
+    int wgs = wg_per_cu > 0 ? wg_per_cu : tiled_wg_per_cu(D, PREMIX, EPI);
+    const int fit = (int)((160 * 1024) / (lds + 256));                 // what the LDS tile allows
+    if (wgs > fit) wgs = fit < 1 ? 1 : fit;
+    long long grid = (long long)wgs * g_num_cus;   // persistent workgroups
     if (grid > tiles) grid = tiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TILED_THREADS), lds, st, a);
     GRHIP_HIP(hipGetLastError());
