@@ -9,7 +9,7 @@ __all__ = [
     "MODE_FAST", "MODE_GENERIC",
     "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
-    "clock_recovery_mm_ff", "binary_slicer_fb", "correlate_access_code_bb",
+    "clock_recovery_mm_ff", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb",
     "fft_vcc", "pfb_channelizer_ccf", "dmr_chain", "run_sync_block",
 ]
 
@@ -447,6 +447,67 @@ class binary_slicer_fb(_Block):
         L = lib()
         L.grhip_binary_slicer_fb_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         n = _check(L.grhip_binary_slicer_fb_work(self._h, int(noutput_items), _ptr(x), _ptr(out)))
+        return out[:n]
+
+
+class pager_slicer_fb(_Block):
+    """pager.slicer_fb(alpha): DC-tracking 4-level slicer (gr-pager/lib/pager_slicer_fb.cc)"""
+    _destroy = "grhip_pager_slicer_fb_destroy"
+
+    def __init__(self, alpha, device=0):
+        _Block.__init__(self)
+        L = lib()
+        L.grhip_pager_slicer_fb_create.argtypes = [C.POINTER(C.c_void_p), C.c_float, C.c_int]
+        _check(L.grhip_pager_slicer_fb_create(C.byref(self._h), float(alpha), int(device)))
+
+    def history(self):
+        return 1
+
+    def decimation(self):
+        return 1
+
+    def work(self, noutput_items, input_items):
+        x = np.ascontiguousarray(input_items, dtype=np.float32)
+        out = np.zeros(noutput_items, dtype=np.uint8)
+        L = lib()
+        L.grhip_pager_slicer_fb_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        n = _check(L.grhip_pager_slicer_fb_work(self._h, int(noutput_items), _ptr(x), _ptr(out)))
+        return out[:n]
+
+    def work_device(self, noutput_items, d_in, d_out, stream=None):
+        L = lib()
+        L.grhip_pager_slicer_fb_work_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        return _check(L.grhip_pager_slicer_fb_work_device(self._h, int(noutput_items), _devptr(d_in), _devptr(d_out),
+                                                          _stream(stream)))
+
+    def dc_offset(self):
+        L = lib()
+        v = C.c_float(0)
+        L.grhip_pager_slicer_fb_dc_offset.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        _check(L.grhip_pager_slicer_fb_dc_offset(self._h, C.byref(v)))
+        return np.float32(v.value)
+
+
+class unpack_k_bits_bb(_Block):
+    """gr.unpack_k_bits_bb(k): k output bytes (one bit each, MSB first) per input byte"""
+    _destroy = "grhip_unpack_k_bits_bb_destroy"
+
+    def __init__(self, k, device=0):
+        _Block.__init__(self)
+        L = lib()
+        L.grhip_unpack_k_bits_bb_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint, C.c_int]
+        _check(L.grhip_unpack_k_bits_bb_create(C.byref(self._h), int(k), int(device)))
+        self.k = int(k)
+
+    def interpolation(self):
+        return self.k
+
+    def work(self, noutput_items, input_items):
+        x = np.ascontiguousarray(input_items, dtype=np.uint8)
+        out = np.zeros(noutput_items, dtype=np.uint8)
+        L = lib()
+        L.grhip_unpack_k_bits_bb_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        n = _check(L.grhip_unpack_k_bits_bb_work(self._h, int(noutput_items), _ptr(x), _ptr(out)))
         return out[:n]
 
 

@@ -67,6 +67,15 @@ struct grhip_clock_recovery_mm_ff : HandleBase {
 
 struct grhip_binary_slicer_fb : HandleBase {};
 
+struct grhip_pager_slicer_fb : HandleBase {
+    float alpha = 0, beta = 1;
+    DevBuf d_avg;
+};
+
+struct grhip_unpack_k_bits_bb : HandleBase {
+    unsigned k = 1;
+};
+
 struct grhip_correlate_access_code_bb : HandleBase {
     CorrParams p;
     unsigned long long flag_bit = 0;
@@ -224,6 +233,128 @@ int grhip_binary_slicer_fb_work(grhip_binary_slicer_fb *h, int noutput_items, co
     hipStream_t st = h->own_stream;
     GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n * 4, hipMemcpyHostToDevice, st));
     if ((rc = launch_binary_slicer(h->stage_in.as<float>(), h->stage_out.as<unsigned char>(), (long long)n, st)))
+        return rc;
+    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, n, hipMemcpyDeviceToHost, st));
+    GRHIP_HIP(hipStreamSynchronize(st));
+    return noutput_items;
+}
+
+// ---- pager_slicer_fb -------------------------------------------------------------
+int grhip_pager_slicer_fb_create(grhip_pager_slicer_fb **h, float alpha, int device)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    auto *b = new (std::nothrow) grhip_pager_slicer_fb();
+    if (!b) return fail(GRHIP_ENOMEM, "alloc");
+    b->alpha = alpha;
+    b->beta = (float)(1.0 - (double)alpha);          // pager_slicer_fb.cc:40
+    int rc = b->init_device(device);
+    if (!rc) rc = b->d_avg.reserve(sizeof(float));
+    if (!rc) { hipError_t e = hipMemset(b->d_avg.p, 0, sizeof(float)); if (e != hipSuccess) rc = fail(GRHIP_ERUNTIME, "memset"); }
+    if (rc) { b->d_avg.release(); b->destroy_base(); delete b; return rc; }
+    *h = b;
+    return GRHIP_OK;
+}
+
+void grhip_pager_slicer_fb_destroy(grhip_pager_slicer_fb *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    h->d_avg.release();
+    h->destroy_base();
+    delete h;
+}
+
+int grhip_pager_slicer_fb_work_device(grhip_pager_slicer_fb *h, int noutput_items, const float *d_in,
+                                      unsigned char *d_out, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    int rc = h->bind();
+    if (rc) return rc;
+    rc = launch_pager_slicer(h->d_avg.as<float>(), 1, h->alpha, h->beta, d_in, 0, d_out, 0, noutput_items,
+                             h->pick(stream));
+    return rc ? rc : noutput_items;
+}
+
+int grhip_pager_slicer_fb_work(grhip_pager_slicer_fb *h, int noutput_items, const float *in, unsigned char *out)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    if (noutput_items == 0) return 0;
+    int rc = h->bind();
+    if (rc) return rc;
+    size_t n = (size_t)noutput_items;
+    if ((rc = h->stage_in.reserve(n * 4))) return rc;
+    if ((rc = h->stage_out.reserve(n))) return rc;
+    hipStream_t st = h->own_stream;
+    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n * 4, hipMemcpyHostToDevice, st));
+    if ((rc = launch_pager_slicer(h->d_avg.as<float>(), 1, h->alpha, h->beta, h->stage_in.as<float>(), 0,
+                                  h->stage_out.as<unsigned char>(), 0, (long long)n, st)))
+        return rc;
+    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, n, hipMemcpyDeviceToHost, st));
+    GRHIP_HIP(hipStreamSynchronize(st));
+    return noutput_items;
+}
+
+int grhip_pager_slicer_fb_dc_offset(grhip_pager_slicer_fb *h, float *dc_offset)
+{
+    if (!h || !dc_offset) return fail(GRHIP_EINVAL, "null argument");
+    int rc = h->bind();
+    if (rc) return rc;
+    GRHIP_HIP(hipDeviceSynchronize());
+    GRHIP_HIP(hipMemcpy(dc_offset, h->d_avg.p, sizeof(float), hipMemcpyDeviceToHost));
+    return GRHIP_OK;
+}
+
+// ---- unpack_k_bits_bb --------------------------------------------------------------
+int grhip_unpack_k_bits_bb_create(grhip_unpack_k_bits_bb **h, unsigned k, int device)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    if (k == 0) return fail(GRHIP_ERANGE, "interpolation must be > 0");          // .cc:45-46
+    if (k > 32) return fail(GRHIP_EINVAL, "k > 32: the reference shifts an unsigned int");
+    auto *b = new (std::nothrow) grhip_unpack_k_bits_bb();
+    if (!b) return fail(GRHIP_ENOMEM, "alloc");
+    b->k = k;
+    int rc = b->init_device(device);
+    if (rc) { b->destroy_base(); delete b; return rc; }
+    *h = b;
+    return GRHIP_OK;
+}
+
+void grhip_unpack_k_bits_bb_destroy(grhip_unpack_k_bits_bb *h)
+{
+    if (!h) return;
+    h->destroy_base();
+    delete h;
+}
+
+int grhip_unpack_k_bits_bb_work_device(grhip_unpack_k_bits_bb *h, int noutput_items, const unsigned char *d_in,
+                                       unsigned char *d_out, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0 || (unsigned)noutput_items % h->k) return fail(GRHIP_EINVAL, "noutput_items must be a multiple of k");
+    int rc = h->bind();
+    if (rc) return rc;
+    rc = launch_unpack_k_bits(h->k, d_in, d_out, noutput_items, h->pick(stream));
+    return rc ? rc : noutput_items;
+}
+
+int grhip_unpack_k_bits_bb_work(grhip_unpack_k_bits_bb *h, int noutput_items, const unsigned char *in,
+                                unsigned char *out)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0 || (unsigned)noutput_items % h->k) return fail(GRHIP_EINVAL, "noutput_items must be a multiple of k");
+    if (noutput_items == 0) return 0;
+    int rc = h->bind();
+    if (rc) return rc;
+    size_t n = (size_t)noutput_items, ni = n / h->k;
+    if ((rc = h->stage_in.reserve(ni))) return rc;
+    if ((rc = h->stage_out.reserve(n))) return rc;
+    hipStream_t st = h->own_stream;
+    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, ni, hipMemcpyHostToDevice, st));
+    if ((rc = launch_unpack_k_bits(h->k, h->stage_in.as<unsigned char>(), h->stage_out.as<unsigned char>(), (long long)n, st)))
         return rc;
     GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, n, hipMemcpyDeviceToHost, st));
     GRHIP_HIP(hipStreamSynchronize(st));

@@ -22,6 +22,10 @@ int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items
               const float *mmse_rev, hipStream_t st);
 
 int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipStream_t st);
+// pager_slicer_fb: d_avg[s] carried in device memory; streams s at in + s*in_stride / out + s*out_stride
+int launch_pager_slicer(float *d_avg, int n_streams, float alpha, float beta, const float *in, long long in_stride,
+                        unsigned char *out, long long out_stride, long long n, hipStream_t st);
+int launch_unpack_k_bits(unsigned k, const unsigned char *in, unsigned char *out, long long noutput_items, hipStream_t st);
 
 // device-resident state of one digital_correlate_access_code_bb instance
 struct CorrState {

@@ -129,6 +129,86 @@ int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items
 }
 
 // ===========================================================================
+// pager_slicer_fb (gr-pager/lib/pager_slicer_fb.cc:47-84).  The DC tracker
+// d_avg = d_avg*beta + x*alpha is a serial float recurrence (bit-exact: two products and
+// one sum, unfused).  One wavefront per stream, windows of 1024 samples: all lanes load
+// the window and form x*alpha in parallel, every lane then walks the recurrence out of
+// LDS redundantly (two dependent operations per sample), and all lanes take the
+// decisions in parallel.
+// ===========================================================================
+constexpr int PS_CH = 1024;
+
+__global__ void __launch_bounds__(64)
+pager_slicer_kernel(float *__restrict__ d_avg, float alpha, float beta, const float *__restrict__ in,
+                    long long in_stride, unsigned char *__restrict__ out, long long out_stride, long long n)
+{
+    __shared__ float s_x[PS_CH], s_t[PS_CH];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const float *__restrict__ x = in + (long long)s * in_stride;
+    unsigned char *__restrict__ y = out + (long long)s * out_stride;
+    float avg = d_avg[s];
+    for (long long base = 0; base < n; base += PS_CH) {
+        const int m = (int)(n - base < PS_CH ? n - base : PS_CH);
+        for (int i = lane; i < m; i += 64) {
+            const float v = x[base + i];
+            s_x[i] = v;
+            s_t[i] = v * alpha;
+        }
+        __syncthreads();
+        for (int i = 0; i < m; ++i) {
+            avg = avg * beta + s_t[i];              // .cc:52
+            s_t[i] = avg;
+        }
+        __syncthreads();
+        for (int i = lane; i < m; i += 64) {
+            const float sample = s_x[i] - s_t[i];   // .cc:53
+            unsigned char d;
+            if (sample > 0) d = (sample > 2.0f) ? 3 : 2;
+            else d = (sample < -2.0f) ? 0 : 1;
+            y[base + i] = d;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) d_avg[s] = avg;
+}
+
+int launch_pager_slicer(float *d_avg, int n_streams, float alpha, float beta, const float *in, long long in_stride,
+                        unsigned char *out, long long out_stride, long long n, hipStream_t st)
+{
+    if (n <= 0 || n_streams <= 0) return GRHIP_OK;
+    hipLaunchKernelGGL(pager_slicer_kernel, dim3(n_streams), dim3(64), 0, st, d_avg, alpha, beta, in, in_stride, out,
+                       out_stride, n);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+// ===========================================================================
+// gr_unpack_k_bits_bb (general/gr_unpack_k_bits_bb.cc:64-69): output n is bit
+// k-1-(n mod k) of input n/k
+// ===========================================================================
+__global__ void __launch_bounds__(256)
+unpack_k_bits_kernel(unsigned k, const unsigned char *__restrict__ in, unsigned char *__restrict__ out, long long n)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const long long q = i / k;
+        const unsigned j = k - 1 - (unsigned)(i - q * k);
+        out[i] = (unsigned char)(((unsigned)in[q] >> j) & 1u);
+    }
+}
+
+int launch_unpack_k_bits(unsigned k, const unsigned char *in, unsigned char *out, long long noutput_items, hipStream_t st)
+{
+    if (noutput_items <= 0) return GRHIP_OK;
+    long long blocks = (noutput_items + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(unpack_k_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, k, in, out, noutput_items);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+// ===========================================================================
 // binary slicer (gr-digital/lib/digital_binary_slicer_fb.cc:54-56)
 // ===========================================================================
 __global__ void __launch_bounds__(256)

@@ -5,6 +5,7 @@
 //   gr_block            gnuradio-core/src/lib/runtime/gr_block.h:63-66,76-84,107-127,153-182
 //   gr_sync_block       gnuradio-core/src/lib/runtime/gr_sync_block.cc:38-68
 //   gr_sync_decimator   gnuradio-core/src/lib/runtime/gr_sync_decimator.cc:38-68
+//   gr_sync_interpolator gnuradio-core/src/lib/runtime/gr_sync_interpolator.cc:30-75
 //   gr_io_signature     gnuradio-core/src/lib/runtime/gr_io_signature.h
 // When building against a real GNU Radio 3.5 tree define GRHIP_USE_GNURADIO and
 // the real headers are used instead (the wrappers only rely on what is here).
@@ -15,6 +16,7 @@
 #include <gr_io_signature.h>
 #include <gr_sync_block.h>
 #include <gr_sync_decimator.h>
+#include <gr_sync_interpolator.h>
 #else
 
 #include <cmath>
@@ -133,6 +135,33 @@ public:
     {
         int r = work(noutput_items, in, out);
         if (r > 0) consume_each(r * decimation()); else consume_each(0);   // gr_sync_decimator.cc:58-66
+        return r;
+    }
+};
+
+// runtime/gr_sync_interpolator.{h,cc}
+class gr_sync_interpolator : public gr_sync_block {
+    unsigned d_interpolation;
+protected:
+    gr_sync_interpolator(const std::string &name, gr_io_signature_sptr in, gr_io_signature_sptr out,
+                         unsigned interpolation)
+        : gr_sync_block(name, in, out), d_interpolation(interpolation)
+    {
+        set_relative_rate(1.0 * interpolation);
+        set_output_multiple(interpolation);                             // gr_sync_interpolator.cc:34-35
+    }
+public:
+    unsigned interpolation() const { return d_interpolation; }
+    void forecast(int noutput_items, gr_vector_int &req) override
+    {
+        for (size_t i = 0; i < req.size(); i++)
+            req[i] = noutput_items / interpolation() + history() - 1;   // gr_sync_interpolator.cc:42-46
+    }
+    int general_work(int noutput_items, gr_vector_int &, gr_vector_const_void_star &in,
+                     gr_vector_void_star &out) override
+    {
+        int r = work(noutput_items, in, out);
+        if (r > 0) consume_each(r / interpolation()); else consume_each(0);   // gr_sync_interpolator.cc:54-62
         return r;
     }
 };

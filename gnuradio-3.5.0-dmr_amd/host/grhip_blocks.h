@@ -243,6 +243,64 @@ inline grhip_binary_slicer_fb_sptr grhip_make_binary_slicer_fb(int device = 0)
     return gnuradio::get_initial_sptr(new grhip_binary_slicer_fb_blk(device));
 }
 
+// pager_slicer_fb (gr-pager/lib/pager_slicer_fb.h:30-58), gr_unpack_k_bits_bb (general/gr_unpack_k_bits_bb.h)
+class grhip_pager_slicer_fb_blk;
+typedef boost::shared_ptr<grhip_pager_slicer_fb_blk> grhip_pager_slicer_fb_sptr;
+class grhip_pager_slicer_fb_blk : public gr_sync_block {
+    grhip_pager_slicer_fb *d_h = nullptr;
+    grhip_pager_slicer_fb_blk(float alpha, int device)
+        : gr_sync_block("slicer_fb", gr_make_io_signature(1, 1, sizeof(float)),
+                        gr_make_io_signature(1, 1, sizeof(unsigned char)))
+    {
+        grhip_detail::check(grhip_pager_slicer_fb_create(&d_h, alpha, device));
+    }
+    friend grhip_pager_slicer_fb_sptr grhip_make_pager_slicer_fb(float, int);
+public:
+    ~grhip_pager_slicer_fb_blk() { grhip_pager_slicer_fb_destroy(d_h); }
+    float dc_offset() const
+    {
+        float v = 0;
+        grhip_detail::check(grhip_pager_slicer_fb_dc_offset(d_h, &v));
+        return v;
+    }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        int r = grhip_pager_slicer_fb_work(d_h, n, (const float *)in[0], (unsigned char *)out[0]);
+        grhip_detail::check(r);
+        return r;
+    }
+};
+inline grhip_pager_slicer_fb_sptr grhip_make_pager_slicer_fb(float alpha, int device = 0)
+{
+    return gnuradio::get_initial_sptr(new grhip_pager_slicer_fb_blk(alpha, device));
+}
+
+class grhip_unpack_k_bits_bb_blk;
+typedef boost::shared_ptr<grhip_unpack_k_bits_bb_blk> grhip_unpack_k_bits_bb_sptr;
+class grhip_unpack_k_bits_bb_blk : public gr_sync_interpolator {
+    grhip_unpack_k_bits_bb *d_h = nullptr;
+    grhip_unpack_k_bits_bb_blk(unsigned k, int device)
+        : gr_sync_interpolator("unpack_k_bits_bb", gr_make_io_signature(1, 1, sizeof(unsigned char)),
+                               gr_make_io_signature(1, 1, sizeof(unsigned char)), k)
+    {
+        // the reference throws std::out_of_range("interpolation must be > 0") (.cc:45-46)
+        grhip_detail::check(grhip_unpack_k_bits_bb_create(&d_h, k, device));
+    }
+    friend grhip_unpack_k_bits_bb_sptr grhip_make_unpack_k_bits_bb(unsigned, int);
+public:
+    ~grhip_unpack_k_bits_bb_blk() { grhip_unpack_k_bits_bb_destroy(d_h); }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        int r = grhip_unpack_k_bits_bb_work(d_h, n, (const unsigned char *)in[0], (unsigned char *)out[0]);
+        grhip_detail::check(r);
+        return r;
+    }
+};
+inline grhip_unpack_k_bits_bb_sptr grhip_make_unpack_k_bits_bb(unsigned k, int device = 0)
+{
+    return gnuradio::get_initial_sptr(new grhip_unpack_k_bits_bb_blk(k, device));
+}
+
 class grhip_correlate_access_code_bb_blk;
 typedef boost::shared_ptr<grhip_correlate_access_code_bb_blk> grhip_correlate_access_code_bb_sptr;
 class grhip_correlate_access_code_bb_blk : public gr_sync_block {

@@ -226,6 +226,40 @@ GRHIP_API int grhip_binary_slicer_fb_work_device(grhip_binary_slicer_fb *h, int 
                                                  const float *d_in, unsigned char *d_out, void *stream);
 
 /* ======================================================================
+ * pager_slicer_fb  (the 4-level symbol decisions a 4FSK chain needs)
+ *   replaces pager_make_slicer_fb(float alpha)
+ *   gr-pager/lib/pager_slicer_fb.h:30-58, pager_slicer_fb.cc:34-84
+ * One-pole DC tracker (d_avg = d_avg*beta + x*alpha, floats) followed by the
+ * decisions {0,1,2,3} at -2, 0, +2 of the DC-free sample.  The tracker is a
+ * serial float recurrence: bit-exact, one wavefront per stream.
+ * ====================================================================== */
+typedef struct grhip_pager_slicer_fb grhip_pager_slicer_fb;
+GRHIP_API int grhip_pager_slicer_fb_create(grhip_pager_slicer_fb **h, float alpha, int device);
+GRHIP_API void grhip_pager_slicer_fb_destroy(grhip_pager_slicer_fb *h);
+GRHIP_API int grhip_pager_slicer_fb_work(grhip_pager_slicer_fb *h, int noutput_items,
+                                         const float *in, unsigned char *out);
+GRHIP_API int grhip_pager_slicer_fb_work_device(grhip_pager_slicer_fb *h, int noutput_items,
+                                                const float *d_in, unsigned char *d_out, void *stream);
+/* pager_slicer_fb::dc_offset() (.h:56); synchronises with the handle's last launch */
+GRHIP_API int grhip_pager_slicer_fb_dc_offset(grhip_pager_slicer_fb *h, float *dc_offset);
+
+/* ======================================================================
+ * gr_unpack_k_bits_bb  (dibits -> bits ahead of the correlator)
+ *   replaces gr_make_unpack_k_bits_bb(unsigned k)
+ *   general/gr_unpack_k_bits_bb.cc:32-74  (gr_sync_interpolator, k outputs per input,
+ *   most significant of the k bits first); GRHIP_ERANGE if k == 0 (.cc:45-46),
+ *   GRHIP_EINVAL if k > 32 (the reference shifts an unsigned int by up to k-1).
+ *   noutput_items must be a multiple of k (the scheduler guarantees it, .cc:72).
+ * ====================================================================== */
+typedef struct grhip_unpack_k_bits_bb grhip_unpack_k_bits_bb;
+GRHIP_API int grhip_unpack_k_bits_bb_create(grhip_unpack_k_bits_bb **h, unsigned k, int device);
+GRHIP_API void grhip_unpack_k_bits_bb_destroy(grhip_unpack_k_bits_bb *h);
+GRHIP_API int grhip_unpack_k_bits_bb_work(grhip_unpack_k_bits_bb *h, int noutput_items,
+                                          const unsigned char *in, unsigned char *out);
+GRHIP_API int grhip_unpack_k_bits_bb_work_device(grhip_unpack_k_bits_bb *h, int noutput_items,
+                                                 const unsigned char *d_in, unsigned char *d_out, void *stream);
+
+/* ======================================================================
  * digital_correlate_access_code_bb
  *   replaces digital_make_correlate_access_code_bb(const std::string&
  *       access_code, int threshold)

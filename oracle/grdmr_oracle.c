@@ -483,6 +483,41 @@ ORC_API void orc_binary_slicer_fb(const float *in, unsigned char *out, size_t n)
 }
 
 /* ------------------------------------------------------------------ */
+/* pager_slicer_fb (gr-pager/lib/pager_slicer_fb.cc:34-84): 4-level      */
+/* slicer behind a one-pole DC tracker.  d_alpha, d_beta, d_avg are       */
+/* floats; d_beta = 1.0 - alpha is formed in double and narrowed (:40).   */
+/* `avg` carries d_avg across calls.                                      */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_pager_slicer_fb(float alpha, float *avg, const float *in, unsigned char *out, size_t n)
+{
+    const float d_alpha = alpha;
+    const float d_beta = (float)(1.0 - (double)alpha);
+    float d_avg = *avg;
+    for (size_t i = 0; i < n; i++) {
+        float sample = in[i];
+        d_avg = d_avg * d_beta + sample * d_alpha;          /* :52 */
+        sample -= d_avg;                                    /* :53 */
+        unsigned char decision;
+        if (sample > 0) decision = (sample > 2.0) ? 3 : 2;  /* :55-60 */
+        else decision = (sample < -2.0) ? 0 : 1;            /* :61-66 */
+        out[i] = decision;
+    }
+    *avg = d_avg;
+}
+
+/* ------------------------------------------------------------------ */
+/* gr_unpack_k_bits_bb (general/gr_unpack_k_bits_bb.cc:57-74)            */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_unpack_k_bits_bb(unsigned k, const unsigned char *in, unsigned char *out, size_t noutput_items)
+{
+    size_t n = 0;
+    for (size_t i = 0; i < noutput_items / k; i++) {
+        unsigned int t = in[i];
+        for (int j = (int)k - 1; j >= 0; j--) out[n++] = (unsigned char)((t >> j) & 0x01);
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* gr_count_bits64 (general/gr_count_bits.cc:75-93)                     */
 /* ------------------------------------------------------------------ */
 static unsigned count_bits32(unsigned x)

@@ -221,6 +221,34 @@ class ClockRecoveryMM:
                     omega_mid=np.float32(self.s.omega_mid))
 
 
+class PagerSlicer:
+    """pager_slicer_fb: state (d_avg) carried across work() calls"""
+
+    def __init__(self, alpha):
+        self.alpha = float(np.float32(alpha))
+        self.avg = C.c_float(0.0)
+
+    def work(self, x):
+        o = _need()
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros(len(x), dtype=np.uint8)
+        o.orc_pager_slicer_fb.argtypes = [C.c_float, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_size_t]
+        o.orc_pager_slicer_fb(self.alpha, C.byref(self.avg), x.ctypes.data, out.ctypes.data, len(x))
+        return out
+
+    def dc_offset(self):
+        return np.float32(self.avg.value)
+
+
+def unpack_k_bits_bb(k, x):
+    o = _need()
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    out = np.zeros(len(x) * k, dtype=np.uint8)
+    o.orc_unpack_k_bits_bb.argtypes = [C.c_uint, C.c_void_p, C.c_void_p, C.c_size_t]
+    o.orc_unpack_k_bits_bb(int(k), x.ctypes.data, out.ctypes.data, len(out))
+    return out
+
+
 def binary_slicer_fb(x):
     o = _need()
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -143,3 +143,59 @@ def test_correlator_state_across_calls(gpu, po):
         outs.append(blk.work(n, bits[pos:pos + n])); pos += n
     outs.append(blk.work(len(bits) - pos, bits[pos:]))
     assert np.array_equal(np.concatenate(outs), ref)
+
+
+@pytest.mark.parametrize("n", [1, 63, 1024, 1025, 100_003])
+def test_pager_slicer_bit_exact_and_state(gpu, po, n):
+    """pager_slicer_fb: decisions and the DC tracker bit-exact against the oracle, state carried across calls"""
+    rng = np.random.default_rng(n)
+    # 4-level symbols with a DC offset and noise, so that all four decisions and the tracker matter
+    x = (rng.integers(0, 4, n) * 2.0 - 3.0 + 0.7 + 0.3 * rng.standard_normal(n)).astype(np.float32)
+    ref_blk = po.PagerSlicer(0.002)
+    blk = gpu.pager_slicer_fb(0.002)
+    cuts = sorted(set([0, n // 3, (2 * n) // 3, n]))
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        got = blk.work(b - a, x[a:b])
+        assert np.array_equal(got, ref_blk.work(x[a:b]))
+    assert blk.dc_offset().tobytes() == ref_blk.dc_offset().tobytes()
+    assert len(blk.work(0, np.zeros(0, np.float32))) == 0
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 8])
+def test_unpack_k_bits(gpu, po, k):
+    rng = np.random.default_rng(k)
+    x = rng.integers(0, 256, 10_007).astype(np.uint8)
+    got = gpu.unpack_k_bits_bb(k).work(len(x) * k, x)
+    assert np.array_equal(got, po.unpack_k_bits_bb(k, x))
+    # the reference QA vector (gr/qa_unpack_k_bits.py:45-54)
+    assert gpu.unpack_k_bits_bb(2).work(8, np.array([2, 3, 0, 1], np.uint8)).tolist() == [1, 0, 1, 1, 0, 0, 0, 1]
+
+
+def test_unpack_k_bits_errors(gpu):
+    with pytest.raises(gpu.GrhipError):
+        gpu.unpack_k_bits_bb(0)              # std::out_of_range("interpolation must be > 0")
+    with pytest.raises(gpu.GrhipError):
+        gpu.unpack_k_bits_bb(2).work(3, np.zeros(2, np.uint8))     # not a multiple of k
+
+
+def test_four_level_chain_tail(gpu, po, wl):
+    """soft 4FSK symbols -> pager_slicer_fb -> unpack_k_bits(2) -> correlate_access_code,
+    every stage on the GPU, equal to the oracle chain"""
+    rng = np.random.default_rng(77)
+    nsym = 50_000
+    dibits = rng.integers(0, 4, nsym)
+    code = wl.access_code_string()                      # 48 bits = 24 dibits
+    code_dibits = [int(code[i:i + 2], 2) for i in range(0, len(code), 2)]
+    for start in range(1000, nsym - 100, 5000):
+        dibits[start:start + len(code_dibits)] = code_dibits
+    soft = (dibits * 2.0 - 3.0 + 0.2 * rng.standard_normal(nsym)).astype(np.float32)
+    sl, up = gpu.pager_slicer_fb(0.001), gpu.unpack_k_bits_bb(2)
+    corr = gpu.correlate_access_code_bb(code, 0)
+    sym = sl.work(nsym, soft)
+    bits = up.work(2 * nsym, sym)
+    out = corr.work(len(bits), bits)
+    o_sym = po.PagerSlicer(0.001).work(soft)
+    o_bits = po.unpack_k_bits_bb(2, o_sym)
+    o_out = po.CorrelateAccessCode(code, 0).work(o_bits)
+    assert np.array_equal(sym, o_sym) and np.array_equal(bits, o_bits) and np.array_equal(out, o_out)
+    assert int((out & 2).sum()) // 2 >= 9               # the planted sync words are found
