@@ -282,6 +282,24 @@ def test_run_captures_batched_vs_oracle(gpu, po, wl, stride_pad, n):
             assert ok, (rep, s, worst)
 
 
+@pytest.mark.parametrize("nout", [1, 5, 8, 9, 2015, 2016, 2017, 4033])
+def test_fused_xlating_demod_small_and_tile_edges(gpu, po, wl, nout):
+    """output counts around the lane (8) and tile (2016 new outputs) granularity, two calls each
+    so that the one-sample carry crosses a call at every size"""
+    c = wl.CFG2
+    n = 2 * nout * c["decim"]
+    x = wl.fsk4_capture(max(n, 4096), stream_id=20)[:n]
+    proto = wl.cfg2_proto_taps()
+    ref = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], x)
+    blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
+    xin = wl.with_history(x, 255)
+    a = blk.work(nout, xin[: nout * 4 + 255])
+    b = blk.work(nout, xin[nout * 4: 2 * nout * 4 + 255])
+    got = np.concatenate([a, b])
+    ok, worst = demod_close(got, ref[: 2 * nout])
+    assert ok, worst
+
+
 def test_fused_xlating_demod_mode_switch_mid_stream(gpu, po, wl):
     """FAST and GENERIC keep the demodulator's one-sample carry in different frames
     (fir_kernels.h, EPI_DEMOD); switching between work() calls converts it"""
