@@ -1,35 +1,36 @@
 // fir_tiled.hip -- the throughput kernel of the FIR family (complex data):
 // gr_fir_ccf / gr_fir_ccc decimating FIR, the composite FIR + rotator of
-// gr_freq_xlating_fir_filter_ccc and the fused quadrature demodulator.
+// gr_freq_xlating_fir_filter_ccc, the fused quadrature demodulator, and (float-pair
+// mode) gr_fir_fff.
 //
 // Shape of the work: y[n] = sum_k c[k] x[nD+k] is a vector x scalar recurrence
 // (wave-uniform taps against per-lane data), VALU-bound at 256 taps,
 // so the design goal is to keep the vector FMA pipes issuing while HBM traffic,
 // LDS staging and the epilogue hide underneath.  No MFMA.
 //
-//  * Persistent 256-lane workgroups (2 per CU) walk tiles of NT = 256*R
-//    consecutive outputs, over all streams of the launch.
-//  * The input tile is fetched from HBM with coalesced 16-byte loads into
-//    REGISTERS one tile ahead: the loads of tile i+1 are issued before the MAC
-//    loop of tile i and land while it runs (branch-free, so no wait at a join).
+//  * Persistent 256-lane workgroups (2 per CU; 4 for plain decimation-1 filters) walk
+//    tiles of NT = 256*R outputs over all streams of the launch; the first two tiles of
+//    a workgroup are static, the rest come from a tile queue (one atomic per tile,
+//    requested two tiles ahead).
+//  * The input tile is fetched from HBM with 16-byte raw buffer loads into REGISTERS
+//    one tile ahead (the hardware range check supplies the history zeros and the end
+//    of the stream: no bounds code, no branch around a load), a share of the loads at
+//    the top of each polyphase pass of the MAC loop.
 //  * The tile is then written to LDS de-interleaved into its D polyphase
 //    components (x_p[m] = x[mD+p]) with one pad slot per R samples, so that the
-//    lane stride is R+1 (odd) 8-byte slots: conflict-free ds_read_b64.
-//  * Each lane keeps R complex accumulators and an R-deep sliding window of
-//    samples in VGPRs: one LDS read feeds R complex MACs (v_pk_fma_f32 with the
-//    tap as the SGPR operand).  Taps and the staging phasor steps are read
-//    through the CONSTANT address space so that they stay scalar loads (s_load)
-//    even though the persistent loop also stores to global memory; the taps of
-//    the next 8 steps are requested one iteration ahead.
+//    lane stride is R+1 (odd) 8-byte slots: conflict-free ds_read_b64.  The pad slots
+//    of component 0 hold the demodulator's arctangent table.
+//  * Each lane keeps R complex accumulators.  Its samples come in blocks of R; a step
+//    multiplies R taps against two blocks (R*R v_pk_fma_f32, tap = SGPR operand).  For
+//    real taps a step is ONE asm statement: the scalar load of the next step's taps,
+//    the FMAs, the wait -- see the MAC loop.
 //  * Real prototype taps (the usual low-pass) take the pre-mix form of the
-//    frequency translation: x'[u] = x[u] * e^{jwu} at staging, real-tap MACs
-//    (half the flops of complex taps), per-output phase correction in the
-//    epilogue.  W[u] is built from a 513-entry lane table times a wave-uniform
-//    step e^{jw 512 i}, so staging reads nothing but the samples.
-//  * Epilogues: rotator multiply with the exact-recurrence phase table
-//    (8 B / output) and the fused quadrature demodulator.  The demodulator's
-//    predecessor of a tile's first output is recomputed by the whole workgroup
-//    (tree-order sum) instead of being exchanged between workgroups.
+//    frequency translation: x'[u] = x[u] * e^{jw(u-D)} at staging (phasors kept in
+//    VGPRs), real-tap MACs: half the flops of complex taps.
+//  * Epilogues: EPI_ROTATE = per-output phase correction of the pre-mix form + rotator
+//    multiply with the exact-recurrence phase table (8 B / output); EPI_DEMOD = the
+//    fused quadrature demodulator working directly on the pre-mixed accumulators, its
+//    y[n-1] made local by overlapping one lane per wave.
 #include <cstdio>
 #include <cstdlib>
 
