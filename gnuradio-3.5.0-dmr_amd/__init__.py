@@ -3,7 +3,7 @@
 Mirrors the names the reference's SWIG layer gives the same blocks
 (gr.fir_filter_ccf, gr.freq_xlating_fir_filter_ccc, gr.quadrature_demod_cf,
 digital.clock_recovery_mm_ff, digital.correlate_access_code_bb,
-digital.binary_slicer_fb, pager.slicer_fb, gr.unpack_k_bits_bb, gr.fft_vcc,
+digital.binary_slicer_fb, pager.slicer_fb, gr.unpack_k_bits_bb, gr.fft_vcc, gr.fft_filter_ccc,
 gr.pfb_channelizer_ccf) with the same
 constructor arguments; `work()` takes/returns numpy arrays with the
 gr_sync_block contract (history items in front of the input).

@@ -10,7 +10,7 @@ __all__ = [
     "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
     "clock_recovery_mm_ff", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb",
-    "fft_vcc", "pfb_channelizer_ccf", "dmr_chain", "run_sync_block",
+    "fft_vcc", "fft_filter_ccc", "pfb_channelizer_ccf", "dmr_chain", "run_sync_block",
 ]
 
 MODE_FAST = 0
@@ -595,6 +595,48 @@ class fft_vcc(_Block):
 # ----------------------------------------------------------------------------
 # gr.pfb_channelizer_ccf
 # ----------------------------------------------------------------------------
+class fft_filter_ccc(_Block):
+    """gr.fft_filter_ccc(decimation, taps): overlap-add fast convolution (history 1, output multiple nsamples)"""
+    _destroy = "grhip_fft_filter_ccc_destroy"
+
+    def __init__(self, decimation, taps, device=0):
+        _Block.__init__(self)
+        L = lib()
+        t = np.ascontiguousarray(taps, dtype=np.complex64)
+        L.grhip_fft_filter_ccc_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+        _check(L.grhip_fft_filter_ccc_create(C.byref(self._h), int(decimation), _ptr(t), len(t), int(device)))
+
+    def history(self):
+        return 1
+
+    def decimation(self):
+        return _check(lib().grhip_fft_filter_ccc_decimation(self._h))
+
+    def nsamples(self):
+        """the block's output multiple"""
+        return _check(lib().grhip_fft_filter_ccc_nsamples(self._h))
+
+    def set_taps(self, taps):
+        t = np.ascontiguousarray(taps, dtype=np.complex64)
+        L = lib()
+        L.grhip_fft_filter_ccc_set_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        _check(L.grhip_fft_filter_ccc_set_taps(self._h, _ptr(t), len(t)))
+
+    def work(self, noutput_items, input_items):
+        x = np.ascontiguousarray(input_items, dtype=np.complex64)
+        out = np.zeros(noutput_items, dtype=np.complex64)
+        L = lib()
+        L.grhip_fft_filter_ccc_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        n = _check(L.grhip_fft_filter_ccc_work(self._h, int(noutput_items), _ptr(x), _ptr(out)))
+        return out[:n]
+
+    def work_device(self, noutput_items, d_in, d_out, stream=None):
+        L = lib()
+        L.grhip_fft_filter_ccc_work_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        return _check(L.grhip_fft_filter_ccc_work_device(self._h, int(noutput_items), _devptr(d_in), _devptr(d_out),
+                                                         _stream(stream)))
+
+
 class pfb_channelizer_ccf(_Block):
     _destroy = "grhip_pfb_channelizer_ccf_destroy"
 

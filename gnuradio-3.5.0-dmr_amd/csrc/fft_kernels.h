@@ -26,4 +26,12 @@ struct PfbArgs {
 };
 int launch_pfb(const PfbArgs &a, hipStream_t st);
 
+// gr_fft_filter_ccc helpers (overlap-add around launch_fft)
+int launch_fftfilt_pack(const float2 *in, float2 *blocks, int nsamples, int fftsize, long long nblk, hipStream_t st);
+int launch_fftfilt_mul(float2 *blocks, const float2 *xformed, int fftsize, long long nblk, hipStream_t st);
+int launch_fftfilt_ola(const float2 *blocks, const float2 *tail, float2 *out, long long nitems, int decim, int nsamples,
+                       int fftsize, int tailsize, hipStream_t st);
+int launch_fftfilt_tail(const float2 *blocks, float2 *tail, long long nblk, int nsamples, int fftsize, int tailsize,
+                        hipStream_t st);
+
 }  // namespace grhip

@@ -515,4 +515,98 @@ int launch_pfb(const PfbArgs &a, hipStream_t st)
     return GRHIP_OK;
 }
 
+// ===========================================================================
+// gr_fft_filter_ccc (filter/gri_fft_filter_ccc_generic.cc:121-169): the pieces around the
+// two transforms.  Blocks are independent except for the tail that block b adds into the
+// head of block b+1, so all blocks of a call are transformed in one batched launch and the
+// overlap-add + decimation is a gather.
+// ===========================================================================
+__global__ void __launch_bounds__(256)
+fftfilt_pack_kernel(const float2 *__restrict__ in, float2 *__restrict__ blocks, int nsamples, int fftsize, long long total)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const long long b = i / fftsize;
+        const int j = (int)(i - b * fftsize);
+        blocks[i] = j < nsamples ? in[b * nsamples + j] : make_float2(0.f, 0.f);      // :128-131
+    }
+}
+
+__global__ void __launch_bounds__(256)
+fftfilt_mul_kernel(float2 *__restrict__ blocks, const float2 *__restrict__ xformed, int fftsize, long long total)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) blocks[i] = cmul_ref(blocks[i], xformed[i % fftsize]);   // :139-141
+}
+
+__global__ void __launch_bounds__(256)
+fftfilt_ola_kernel(const float2 *__restrict__ blocks, const float2 *__restrict__ tail, float2 *__restrict__ out,
+                   long long nitems, int decim, int nsamples, int fftsize, int tailsize)
+{
+    long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; o < nitems; o += stride) {
+        const long long i = o * decim;                      // position in the full-rate overlap-added sequence
+        const long long b = i / nsamples;
+        const int j = (int)(i - b * nsamples);
+        float2 v = blocks[b * fftsize + j];
+        if (j < tailsize) {                                 // :147-148 outbuf[j] += d_tail[j]
+            const float2 t = b > 0 ? blocks[(b - 1) * fftsize + nsamples + j] : tail[j];
+            v.x += t.x; v.y += t.y;
+        }
+        out[o] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+fftfilt_tail_kernel(const float2 *__restrict__ blocks, float2 *__restrict__ tail, long long nblk, int nsamples,
+                    int fftsize, int tailsize)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < tailsize) tail[j] = blocks[(nblk - 1) * fftsize + nsamples + j];            // :160-161
+}
+
+static unsigned grid_for(long long n)
+{
+    long long b = (n + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+int launch_fftfilt_pack(const float2 *in, float2 *blocks, int nsamples, int fftsize, long long nblk, hipStream_t st)
+{
+    const long long total = nblk * fftsize;
+    hipLaunchKernelGGL(fftfilt_pack_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, blocks, nsamples, fftsize, total);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+int launch_fftfilt_mul(float2 *blocks, const float2 *xformed, int fftsize, long long nblk, hipStream_t st)
+{
+    const long long total = nblk * fftsize;
+    hipLaunchKernelGGL(fftfilt_mul_kernel, dim3(grid_for(total)), dim3(256), 0, st, blocks, xformed, fftsize, total);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+int launch_fftfilt_ola(const float2 *blocks, const float2 *tail, float2 *out, long long nitems, int decim, int nsamples,
+                       int fftsize, int tailsize, hipStream_t st)
+{
+    hipLaunchKernelGGL(fftfilt_ola_kernel, dim3(grid_for(nitems)), dim3(256), 0, st, blocks, tail, out, nitems, decim,
+                       nsamples, fftsize, tailsize);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+int launch_fftfilt_tail(const float2 *blocks, float2 *tail, long long nblk, int nsamples, int fftsize, int tailsize,
+                        hipStream_t st)
+{
+    if (tailsize <= 0) return GRHIP_OK;
+    hipLaunchKernelGGL(fftfilt_tail_kernel, dim3((tailsize + 255) / 256), dim3(256), 0, st, blocks, tail, nblk,
+                       nsamples, fftsize, tailsize);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
 }  // namespace grhip

@@ -368,6 +368,9 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
         decode(nxt, s_nxt, b_nxt);
 
         STAMP(7);
+#if GRHIP_EXP & 32
+        __builtin_amdgcn_s_setprio(3);      // the latency-bound phases take issue slots as soon as they can use them
+#endif
         stage(s, bidx);
         STAMP(0);
         __syncthreads();
@@ -401,6 +404,9 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
         const int lane_base = (tl + 1) * R + (tl + 1);     // slot of mm = (tl+1)R
         const int nb = Tq >> LOGR;                         // steps per pass
         tapvec hcur = *reinterpret_cast<const tapvec __attribute__((address_space(4))) *>(hp);
+#if GRHIP_EXP & 32
+        __builtin_amdgcn_s_setprio(0);      // the MAC loop fills what is left
+#endif
 
         // Real taps: one step is ONE asm statement -- the scalar load of the next step's
         // taps, the 64 packed FMAs (tap = one half of an SGPR pair, chosen with op_sel) and
@@ -482,6 +488,9 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
         for (int r = 0; r < R; ++r) acc[r] = make_float2(av[r].x, av[r].y);
 
         STAMP(4);
+#if GRHIP_EXP & 32
+        __builtin_amdgcn_s_setprio(3);
+#endif
         // ---------------- epilogue ---------------------------------------------------
         const long long nl = n0 + (long long)tl * R;         // first output of this lane
         if (PREMIX && !DIRECT) {

@@ -368,6 +368,39 @@ inline grhip_fft_vcc_sptr grhip_make_fft_vcc(int fft_size, bool forward, const s
 // ---------------------------------------------------------------------------
 // gr_pfb_channelizer_ccf  (numchans inputs, one output of numchans-complex vectors)
 // ---------------------------------------------------------------------------
+// gr_fft_filter_ccc (filter/gr_fft_filter_ccc.h): gr_sync_decimator, history 1, output multiple nsamples
+class grhip_fft_filter_ccc_blk;
+typedef boost::shared_ptr<grhip_fft_filter_ccc_blk> grhip_fft_filter_ccc_sptr;
+class grhip_fft_filter_ccc_blk : public gr_sync_decimator {
+    grhip_fft_filter_ccc *d_h = nullptr;
+    grhip_fft_filter_ccc_blk(int decimation, const std::vector<gr_complex> &taps, int device)
+        : gr_sync_decimator("fft_filter_ccc", gr_make_io_signature(1, 1, sizeof(gr_complex)),
+                            gr_make_io_signature(1, 1, sizeof(gr_complex)), decimation)
+    {
+        grhip_detail::check(grhip_fft_filter_ccc_create(&d_h, decimation, (const float *)taps.data(), taps.size(), device));
+        set_history(1);
+        set_output_multiple(grhip_fft_filter_ccc_nsamples(d_h));          // gr_fft_filter_ccc.cc:69
+    }
+    friend grhip_fft_filter_ccc_sptr grhip_make_fft_filter_ccc(int, const std::vector<gr_complex> &, int);
+public:
+    ~grhip_fft_filter_ccc_blk() { grhip_fft_filter_ccc_destroy(d_h); }
+    void set_taps(const std::vector<gr_complex> &taps)
+    {
+        grhip_detail::check(grhip_fft_filter_ccc_set_taps(d_h, (const float *)taps.data(), taps.size()));
+    }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        int r = grhip_fft_filter_ccc_work(d_h, n, in[0], out[0]);
+        grhip_detail::check(r);
+        if (r == 0) set_output_multiple(grhip_fft_filter_ccc_nsamples(d_h));   // .cc:113-118
+        return r;
+    }
+};
+inline grhip_fft_filter_ccc_sptr grhip_make_fft_filter_ccc(int decimation, const std::vector<gr_complex> &taps, int device = 0)
+{
+    return gnuradio::get_initial_sptr(new grhip_fft_filter_ccc_blk(decimation, taps, device));
+}
+
 class grhip_pfb_channelizer_ccf_blk;
 typedef boost::shared_ptr<grhip_pfb_channelizer_ccf_blk> grhip_pfb_channelizer_ccf_sptr;
 class grhip_pfb_channelizer_ccf_blk : public gr_block {

@@ -303,6 +303,28 @@ GRHIP_API int grhip_fft_vcc_work_device(grhip_fft_vcc *h, int noutput_items, con
                                         void *d_out, void *stream);
 
 /* ======================================================================
+ * gr_fft_filter_ccc  
+ *   replaces gr_make_fft_filter_ccc(int decimation, const std::vector<gr_complex>& taps)
+ *   filter/gr_fft_filter_ccc.cc:46-128, filter/gri_fft_filter_ccc_generic.cc:63-170
+ * Overlap-add fast convolution with the reference's sizes (fftsize = 2*2^ceil(log2 ntaps),
+ * nsamples = fftsize - ntaps + 1 = the block's output multiple), taps pre-scaled by
+ * 1/fftsize, tail carried between blocks and calls.  gr_sync_decimator, history 1.
+ * noutput_items must be a multiple of nsamples (the reference asserts it, .cc:121).
+ * set_taps takes effect at the next work call, which returns 0 (.cc:113-118) and clears
+ * the tail (generic.cc:69-71).  ntaps <= 4096 (fftsize <= 8192).
+ * ====================================================================== */
+typedef struct grhip_fft_filter_ccc grhip_fft_filter_ccc;
+GRHIP_API int grhip_fft_filter_ccc_create(grhip_fft_filter_ccc **h, int decimation, const float *taps,
+                                          size_t ntaps, int device);
+GRHIP_API void grhip_fft_filter_ccc_destroy(grhip_fft_filter_ccc *h);
+GRHIP_API int grhip_fft_filter_ccc_set_taps(grhip_fft_filter_ccc *h, const float *taps, size_t ntaps);
+GRHIP_API int grhip_fft_filter_ccc_nsamples(const grhip_fft_filter_ccc *h);   /* output multiple */
+GRHIP_API int grhip_fft_filter_ccc_decimation(const grhip_fft_filter_ccc *h);
+GRHIP_API int grhip_fft_filter_ccc_work(grhip_fft_filter_ccc *h, int noutput_items, const void *in, void *out);
+GRHIP_API int grhip_fft_filter_ccc_work_device(grhip_fft_filter_ccc *h, int noutput_items, const void *d_in,
+                                               void *d_out, void *stream);
+
+/* ======================================================================
  * gr_pfb_channelizer_ccf
  *   replaces gr_make_pfb_channelizer_ccf(unsigned numchans,
  *       const std::vector<float>& taps, float oversample_rate)

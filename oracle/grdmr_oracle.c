@@ -668,6 +668,84 @@ ORC_API void orc_fft_vcc(unsigned fft_size, int forward, const float *window, un
 }
 
 /* ------------------------------------------------------------------ */
+/* gr_fft_filter_ccc / gri_fft_filter_ccc_generic          */
+/* filter/gri_fft_filter_ccc_generic.cc:63-170: overlap-ADD fast          */
+/* convolution, fftsize = 2 * 2^ceil(log2 ntaps), nsamples = fftsize -    */
+/* ntaps + 1, taps pre-scaled by 1/fftsize, tail carried between blocks.  */
+/* The transforms are FFTW in the reference (unpinned, see orc_fft_vcc):  */
+/* here a double DFT rounded once to float at FFTW's output.              */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int decim, ntaps, fftsize, nsamples;
+    float *xformed;      /* 2*fftsize */
+    float *tail;         /* 2*(ntaps-1) */
+} orc_fftfilt;
+
+static void fftfilt_xform(int n, int forward, const float *in, float *out)
+{
+    double *xr = (double *)calloc((size_t)n * 4, sizeof(double));
+    double *xi = xr + n, *yr = xi + n, *yi = yr + n;
+    for (int i = 0; i < n; i++) { xr[i] = in[2 * i]; xi[i] = in[2 * i + 1]; }
+    dft_double(xr, xi, yr, yi, (unsigned)n, forward);
+    for (int i = 0; i < n; i++) { out[2 * i] = (float)yr[i]; out[2 * i + 1] = (float)yi[i]; }
+    free(xr);
+}
+
+ORC_API void orc_fft_filter_free(orc_fftfilt *f)
+{
+    if (!f) return;
+    free(f->xformed); free(f->tail); free(f);
+}
+
+ORC_API orc_fftfilt *orc_fft_filter_new(int decimation, const float *taps, unsigned ntaps)
+{
+    if (decimation < 1 || ntaps < 1) return NULL;
+    orc_fftfilt *f = (orc_fftfilt *)calloc(1, sizeof(*f));
+    f->decim = decimation; f->ntaps = (int)ntaps;
+    f->fftsize = (int)(2 * pow(2.0, ceil(log((double)ntaps) / log(2.0))));      /* :104 */
+    f->nsamples = f->fftsize - f->ntaps + 1;                                     /* :105 */
+    f->xformed = (float *)calloc(2 * (size_t)f->fftsize, sizeof(float));
+    f->tail = (float *)calloc(2 * (size_t)(ntaps > 1 ? ntaps - 1 : 1), sizeof(float));
+    float *in = (float *)calloc(2 * (size_t)f->fftsize, sizeof(float));
+    float scale = 1.0 / f->fftsize;                                              /* :76 */
+    for (unsigned i = 0; i < ntaps; i++) { in[2 * i] = taps[2 * i] * scale; in[2 * i + 1] = taps[2 * i + 1] * scale; }
+    fftfilt_xform(f->fftsize, 1, in, f->xformed);
+    free(in);
+    return f;
+}
+
+ORC_API int orc_fft_filter_nsamples(const orc_fftfilt *f) { return f->nsamples; }
+
+/* filter(): nitems outputs from nitems*decimation inputs (a multiple of nsamples) (:121-169) */
+ORC_API int orc_fft_filter_filter(orc_fftfilt *f, int nitems, const float *input, float *output)
+{
+    int dec_ctr = 0, j;
+    int ninput_items = nitems * f->decim;
+    int tailsize = f->ntaps - 1;
+    float *a = (float *)calloc(2 * (size_t)f->fftsize, sizeof(float));
+    float *c = (float *)calloc(2 * (size_t)f->fftsize, sizeof(float));
+    float *o = (float *)calloc(2 * (size_t)f->fftsize, sizeof(float));
+    for (int i = 0; i < ninput_items; i += f->nsamples) {
+        memcpy(a, &input[2 * (size_t)i], sizeof(float) * 2 * f->nsamples);
+        for (j = f->nsamples; j < f->fftsize; j++) { a[2 * j] = 0; a[2 * j + 1] = 0; }
+        fftfilt_xform(f->fftsize, 1, a, o);
+        for (j = 0; j < f->fftsize; j++)                                        /* c[j] = a[j] * b[j] */
+            cmul(o[2 * j], o[2 * j + 1], f->xformed[2 * j], f->xformed[2 * j + 1], &c[2 * j], &c[2 * j + 1]);
+        fftfilt_xform(f->fftsize, 0, c, o);
+        for (j = 0; j < tailsize; j++) { o[2 * j] += f->tail[2 * j]; o[2 * j + 1] += f->tail[2 * j + 1]; }
+        j = dec_ctr;
+        while (j < f->nsamples) {
+            *output++ = o[2 * j]; *output++ = o[2 * j + 1];
+            j += f->decim;
+        }
+        dec_ctr = (j - f->nsamples);
+        memcpy(f->tail, o + 2 * (size_t)f->nsamples, sizeof(float) * 2 * tailsize);
+    }
+    free(a); free(c); free(o);
+    return nitems;
+}
+
+/* ------------------------------------------------------------------ */
 /* gr_pfb_channelizer_ccf (filter/gr_pfb_channelizer_ccf.cc:44-200)     */
 /* ------------------------------------------------------------------ */
 typedef struct {

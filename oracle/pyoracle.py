@@ -303,6 +303,41 @@ def fft_vcc(fft_size, forward, window, shift, x):
     return out
 
 
+class FftFilterCcc:
+    """gr_fft_filter_ccc / gri_fft_filter_ccc_generic restatement (overlap-add)"""
+
+    def __init__(self, decimation, taps):
+        o = _need()
+        t = np.ascontiguousarray(taps, dtype=np.complex64)
+        o.orc_fft_filter_new.restype = C.c_void_p
+        o.orc_fft_filter_new.argtypes = [C.c_int, C.c_void_p, C.c_uint]
+        self.h = o.orc_fft_filter_new(int(decimation), t.ctypes.data, len(t))
+        if not self.h:
+            raise ValueError("bad fft_filter arguments")
+        o.orc_fft_filter_nsamples.argtypes = [C.c_void_p]
+        self.nsamples = o.orc_fft_filter_nsamples(self.h)
+        self.decim = int(decimation)
+
+    def __del__(self):
+        try:
+            o = _need()
+            o.orc_fft_filter_free.argtypes = [C.c_void_p]
+            if self.h:
+                o.orc_fft_filter_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def filter(self, nitems, x):
+        o = _need()
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        assert len(x) >= nitems * self.decim and (nitems * self.decim) % self.nsamples == 0
+        out = np.zeros(nitems, dtype=np.complex64)
+        o.orc_fft_filter_filter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        o.orc_fft_filter_filter(self.h, int(nitems), x.ctypes.data, out.ctypes.data)
+        return out
+
+
 class PfbChannelizer:
     """gr_pfb_channelizer_ccf restatement."""
 

@@ -142,3 +142,48 @@ def test_pfb_tone_lands_in_its_channel_full_size(gpu, wl):
         out, _ = blk.general_work(nout, streams)
         p = (np.abs(out[1000:]) ** 2).mean(0)
         assert np.argmax(p) == k and p[k] > 100 * np.delete(p, k).max()
+
+
+@pytest.mark.parametrize("ntaps,decim", [(1, 1), (7, 1), (64, 2), (256, 4), (255, 5), (1000, 1)])
+def test_fft_filter_ccc_vs_oracle_and_direct_form(gpu, po, ntaps, decim):
+    """gr_fft_filter_ccc (overlap-add): equal to the oracle's restatement of
+    gri_fft_filter_ccc_generic within the FFT tolerance (the reference's transforms are FFTW:
+    unpinned), equal to the direct-form FIR it stands for, tail carried across calls"""
+    rng = np.random.default_rng(ntaps + decim)
+    taps = _rc(rng, ntaps)
+    ref_blk = po.FftFilterCcc(decim, taps)
+    blk = gpu.fft_filter_ccc(decim, taps)
+    ns = blk.nsamples()
+    assert ns == ref_blk.nsamples and blk.decimation() == decim and blk.history() == 1
+    nout = 6 * ns
+    x = _rc(rng, nout * decim)
+    ref = ref_blk.filter(nout, x)
+    # three calls of 1, 2 and 3 output multiples
+    got = np.concatenate([blk.work(ns, x[: ns * decim]), blk.work(2 * ns, x[ns * decim: 3 * ns * decim]),
+                          blk.work(3 * ns, x[3 * ns * decim:])])
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-6 * np.log2(2 * ns) * scale
+    # the function it computes: y[n] = sum_k taps[k] x[n*decim - k] with zeros before the stream
+    xin = np.concatenate([np.zeros(ntaps - 1, np.complex64), x])
+    direct = po.fir_ccc(taps, xin, nout, decim)
+    assert np.abs(got - direct).max() <= 1e-5 * max(np.abs(direct).max(), 1e-3 * np.abs(taps).sum())
+    with pytest.raises(gpu.GrhipError):
+        blk.work(ns + 1, x)                      # not a multiple of nsamples (the reference asserts)
+
+
+def test_fft_filter_ccc_set_taps(gpu, po):
+    rng = np.random.default_rng(3)
+    t1, t2 = _rc(rng, 33), _rc(rng, 200)
+    blk = gpu.fft_filter_ccc(1, t1)
+    ns1 = blk.nsamples()
+    x = _rc(rng, 4096)
+    blk.work(ns1, x[:ns1])
+    blk.set_taps(t2)
+    assert len(blk.work(ns1, x[:ns1])) == 0      # takes effect, produces nothing (gr_fft_filter_ccc.cc:113-118)
+    ns2 = blk.nsamples()
+    assert ns2 == po.FftFilterCcc(1, t2).nsamples and ns2 != ns1
+    got = blk.work(ns2, x[:ns2])                 # tail was cleared by set_taps
+    ref = po.FftFilterCcc(1, t2).filter(ns2, x[:ns2])
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    with pytest.raises(gpu.GrhipError):
+        gpu.fft_filter_ccc(1, _rc(rng, 5000))    # would need a 16384-point FFT

@@ -103,3 +103,12 @@ xs = torch.randn((M * per, 2), device=dev)
 yo = torch.empty((nout * M, 2), device=dev)
 pf.general_work_device(nout, xs, per, yo, st)       # first call returns 0 (d_updated)
 report("pfb_channelizer_ccf M=8 256t", timeit(lambda: pf.general_work_device(nout, xs, per, yo, st)), nout * M, 16)
+
+# gr_fft_filter_ccc: overlap-add, 256 complex taps -> 512-point transforms, 257 samples per block
+tp = (wl.cfg2_proto_taps() * np.exp(1j * 0.01 * np.arange(256))).astype(np.complex64)
+blk = g.fft_filter_ccc(1, tp)
+ns = blk.nsamples()
+n = ns * 65536
+x = torch.randn((n, 2), device=dev)
+y = torch.empty((n, 2), device=dev)
+report("fft_filter_ccc 256t D=1 (overlap-add, 512-pt)", timeit(lambda: blk.work_device(n, x, y, st), reps=20), n, 16)
