@@ -34,25 +34,25 @@ fft_kernel(int N, int shift, const float *__restrict__ window, const float2 *__r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float2 *A = (float2 *)smem;
     float2 *B = A + N;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, nthr = blockDim.x;      // N/4 lanes (64..256): small transforms get more workgroups per CU
     const float2 *__restrict__ x = in + (long long)blockIdx.x * N;
     float2 *__restrict__ y = out + (long long)blockIdx.x * N;
 
     // ---- load (gr_fft_vcc_fftw.cc:68-83)
     if (window) {
-        for (int i = t; i < N; i += 256) {
+        for (int i = t; i < N; i += nthr) {
             float2 v = x[i];
             float w = window[i];
             A[i] = make_float2(v.x * w, v.y * w);
         }
     } else if (!FWD && shift) {
         const int len = N / 2;                 // floor(N/2.0); dst[k] = in[(k+len) mod N]
-        for (int i = t; i < N; i += 256) {
+        for (int i = t; i < N; i += nthr) {
             int src = i + len; if (src >= N) src -= N;
             A[i] = x[src];
         }
     } else {
-        for (int i = t; i < N; i += 256) A[i] = x[i];
+        for (int i = t; i < N; i += nthr) A[i] = x[i];
     }
     __syncthreads();
 
@@ -62,7 +62,7 @@ fft_kernel(int N, int shift, const float *__restrict__ window, const float2 *__r
     const int T4 = N >> 2;
     while (p * 4 <= N) {
         const int tstep = N / (4 * p);         // twiddle index step
-        for (int i = t; i < T4; i += 256) {
+        for (int i = t; i < T4; i += nthr) {
             const int k = i & (p - 1);
             const int j = ((i - k) << 2) + k;
             const int m = k * tstep;
@@ -93,7 +93,7 @@ fft_kernel(int N, int shift, const float *__restrict__ window, const float2 *__r
     if (p < N) {                                // one radix-2 pass, p == N/2
         const int T2 = N >> 1;
         const int tstep = N / (2 * p);
-        for (int i = t; i < T2; i += 256) {
+        for (int i = t; i < T2; i += nthr) {
             const int k = i & (p - 1);
             const int j = ((i - k) << 1) + k;
             float2 u0 = src[i];
@@ -109,12 +109,12 @@ fft_kernel(int N, int shift, const float *__restrict__ window, const float2 *__r
     // ---- store (gr_fft_vcc_fftw.cc:89-96)
     if (FWD && shift) {
         const int len = (N + 1) / 2;            // ceil(N/2.0); out[k] = fft[(k+len) mod N]
-        for (int i = t; i < N; i += 256) {
+        for (int i = t; i < N; i += nthr) {
             int s = i + len; if (s >= N) s -= N;
             y[i] = src[s];
         }
     } else {
-        for (int i = t; i < N; i += 256) y[i] = src[i];
+        for (int i = t; i < N; i += nthr) y[i] = src[i];
     }
 }
 
@@ -256,6 +256,7 @@ int launch_fft(int N, int forward, int shift, const float *window, const float2 
         return GRHIP_OK;
     }
     size_t lds = (size_t)N * 2 * sizeof(float2);
+    const int nthr = N / 4 >= 256 ? 256 : (N / 4 <= 64 ? 64 : N / 4);
     static size_t cfg_f = 0, cfg_b = 0;
     if (forward) {
         if (lds > 48 * 1024 && lds > cfg_f) {
@@ -263,7 +264,7 @@ int launch_fft(int N, int forward, int shift, const float *window, const float2 
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             cfg_f = lds;
         }
-        hipLaunchKernelGGL(fft_kernel<true>, dim3((unsigned)nvec), dim3(256), lds, st, N, shift, window,
+        hipLaunchKernelGGL(fft_kernel<true>, dim3((unsigned)nvec), dim3(nthr), lds, st, N, shift, window,
                            twiddle, in, out);
     } else {
         if (lds > 48 * 1024 && lds > cfg_b) {
@@ -271,7 +272,7 @@ int launch_fft(int N, int forward, int shift, const float *window, const float2 
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             cfg_b = lds;
         }
-        hipLaunchKernelGGL(fft_kernel<false>, dim3((unsigned)nvec), dim3(256), lds, st, N, shift, window,
+        hipLaunchKernelGGL(fft_kernel<false>, dim3((unsigned)nvec), dim3(nthr), lds, st, N, shift, window,
                            twiddle, in, out);
     }
     GRHIP_HIP(hipGetLastError());
