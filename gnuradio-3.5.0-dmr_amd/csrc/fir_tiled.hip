@@ -280,7 +280,8 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
             if (part >= 0 && i / PER != part) continue;
             // rounds past the end of the tile (short filters, small decimation) are pointed
             // out of range: zeros, no memory traffic, still no branch around a load
-            const int vo = (i * 2 * TILED_THREADS - 1 < Lu) ? voff + i * (LANE_BYTES * TILED_THREADS) : 0x7ffff000;
+            constexpr int INSIDE = NTC * D / (2 * TILED_THREADS);      // rounds that every tile needs in full
+            const int vo = (i < INSIDE || i * 2 * TILED_THREADS - 1 < Lu) ? voff + i * (LANE_BYTES * TILED_THREADS) : 0x7ffff000;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
             const f32x4 f = __builtin_bit_cast(f32x4, v);
             pf[i] = make_float4(f[0], f[1], f[2], f[3]);
@@ -454,9 +455,6 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
 #else
 #pragma unroll
         for (int p = 0; p < D; ++p) {
-#if !(GRHIP_EXP & 4)
-            fetch(rsrc_n, voff_n, p);       // p is a compile-time constant: the pass loop is unrolled
-#endif
             const f32x2 *xp = reinterpret_cast<const f32x2 *>(xs) + p * PS + lane_base;
             f32x2 wA[R], wB[R], wC[R];
             auto load_blk = [&](f32x2 (&dst)[R], int blk) {
@@ -472,6 +470,11 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
             };
             load_blk(wA, 0);
             load_blk(wB, 1);
+#if !(GRHIP_EXP & 4)
+            // this pass's share of the next tile's HBM loads, issued while the first two sample
+            // blocks are on their way from LDS (p is a compile-time constant: the pass loop is unrolled)
+            fetch(rsrc_n, voff_n, p);
+#endif
             int k = 0;
             for (; k + 3 <= nb; k += 3) {
                 step(wA, wB, wC, k);
