@@ -383,3 +383,46 @@ def test_fir_fff_fast_mode(gpu, po, ntaps, decim, n):
     ti = rng.integers(-4, 4, ntaps).astype(np.float32)
     blk2 = gpu.fir_filter_fff(decim, ti)
     assert np.array_equal(blk2.work(n, xi), po.fir_fff(ti, xi, n, decim))
+
+
+def test_fir_random_shapes_fast_mode(gpu, po):
+    """a seeded sweep over kind / tap count / decimation / output count / call chunking:
+    tap counts around the step (8) and triple-step (24) granularity of the MAC loop, above the
+    tiled kernel's 1024-tap limit (generic-order fallback), output counts around the tile"""
+    rng = np.random.default_rng(20261004)
+    kinds = ["ccf", "ccc", "fff"]
+    for case in range(48):
+        kind = kinds[case % 3]
+        ntaps = int(rng.choice([1, 2, 7, 8, 9, 23, 24, 25, 63, 64, 65, 191, 192, 193, 257, 500, 1023, 1025, 1500]))
+        decim = int(rng.choice([1, 1, 2, 3, 4]))
+        n = int(rng.choice([1, 8, 9, 511, 2015, 2016, 2017, 2048, 4097, 12345]))
+        nin = n * decim + ntaps - 1
+        if kind == "fff":
+            x = rng.uniform(-1, 1, nin).astype(np.float32)
+            taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+            blk = gpu.fir_filter_fff(decim, taps)
+            ref = po.fir_fff(taps, x, n, decim)
+            bound = np.abs(taps).sum()
+        elif kind == "ccf":
+            x = _rand_c(rng, nin)
+            taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+            blk = gpu.fir_filter_ccf(decim, taps)
+            ref = po.fir_ccf(taps, x, n, decim)
+            bound = np.abs(taps).sum()
+        else:
+            x = _rand_c(rng, nin)
+            taps = _rand_c(rng, ntaps)
+            blk = gpu.fir_filter_ccc(decim, taps)
+            ref = po.fir_ccc(taps, x, n, decim)
+            bound = np.abs(taps).sum() * np.sqrt(2)
+        blk.set_mode(gpu.MODE_FAST)
+        # two calls when possible: the second starts in the middle of the stream
+        n1 = n // 2
+        parts = []
+        if n1 > 0:
+            parts.append(blk.work(n1, x[: n1 * decim + ntaps - 1]))
+        parts.append(blk.work(n - n1, x[n1 * decim:]))
+        got = np.concatenate(parts)
+        assert got.shape == ref.shape, (kind, ntaps, decim, n)
+        err = np.abs(got - ref).max()
+        assert err <= TOL * max(np.abs(ref).max(), 1e-3 * bound), (kind, ntaps, decim, n, err)
