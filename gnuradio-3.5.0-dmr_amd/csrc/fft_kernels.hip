@@ -130,6 +130,13 @@ fft_kernel(int N, int shift, const float *__restrict__ window, const float2 *__r
 __device__ __forceinline__ float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
+// complex product in two packed instructions (device_math.h)
+__device__ __forceinline__ float2 cmul2(float2 a, float2 b)
+{
+    const f32x2_t r = cmul_pk(f32x2_t{a.x, a.y}, f32x2_t{b.x, b.y});
+    return make_float2(r.x, r.y);
+}
+
 // DFT of 4 points in place (forward: W4 = -i)
 template <bool FWD>
 __device__ __forceinline__ void radix4(float2 &a, float2 &b, float2 &c, float2 &d)
@@ -153,15 +160,15 @@ __device__ __forceinline__ void dft16(float2 (&v)[16])
     const float2 w1 = make_float2(C1, sg * S1), w2 = make_float2(H, sg * H), w3 = make_float2(S1, sg * C1);
     const float2 w6 = make_float2(-H, sg * H), w9 = make_float2(-C1, -sg * S1);
     // a[c][r] *= W16^{c r}
-    v[1 + 4] = cmul_fma(v[1 + 4], w1);
-    v[1 + 8] = cmul_fma(v[1 + 8], w2);
-    v[1 + 12] = cmul_fma(v[1 + 12], w3);
-    v[2 + 4] = cmul_fma(v[2 + 4], w2);
+    v[1 + 4] = cmul2(v[1 + 4], w1);
+    v[1 + 8] = cmul2(v[1 + 8], w2);
+    v[1 + 12] = cmul2(v[1 + 12], w3);
+    v[2 + 4] = cmul2(v[2 + 4], w2);
     v[2 + 8] = FWD ? make_float2(v[2 + 8].y, -v[2 + 8].x) : make_float2(-v[2 + 8].y, v[2 + 8].x);   // W16^4 = -/+ i
-    v[2 + 12] = cmul_fma(v[2 + 12], w6);
-    v[3 + 4] = cmul_fma(v[3 + 4], w3);
-    v[3 + 8] = cmul_fma(v[3 + 8], w6);
-    v[3 + 12] = cmul_fma(v[3 + 12], w9);
+    v[2 + 12] = cmul2(v[2 + 12], w6);
+    v[3 + 4] = cmul2(v[3 + 4], w3);
+    v[3 + 8] = cmul2(v[3 + 8], w6);
+    v[3 + 12] = cmul2(v[3 + 12], w9);
 #pragma unroll
     for (int r = 0; r < 4; ++r) radix4<FWD>(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);  // v[4r + s] = X[r + 4s]
     // un-permute: X[m], m = r + 4s, sits at 4r + s
@@ -217,7 +224,7 @@ fft4096_kernel(int shift, const float *__restrict__ window, const float2 *__rest
         for (int q = 0; q < 16; ++q) v[q] = S[pad(t + 256 * q)];
         __syncthreads();                               // every lane has read before anyone writes
 #pragma unroll
-        for (int q = 1; q < 16; ++q) v[q] = cmul_fma(v[q], w[q]);
+        for (int q = 1; q < 16; ++q) v[q] = cmul2(v[q], w[q]);
         dft16<FWD>(v);
         const int j = (t - k) * 16 + k;
 #pragma unroll
@@ -233,7 +240,7 @@ fft4096_kernel(int shift, const float *__restrict__ window, const float2 *__rest
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = S[pad(t + 256 * q)];
 #pragma unroll
-        for (int q = 1; q < 16; ++q) v[q] = cmul_fma(v[q], w[q]);
+        for (int q = 1; q < 16; ++q) v[q] = cmul2(v[q], w[q]);
         dft16<FWD>(v);
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
