@@ -18,6 +18,12 @@ struct grhip_fft_filter_ccc : HandleBase {
     std::vector<std::complex<float>> new_taps;
     bool updated = false;
     DevBuf d_twiddle, d_xformed, d_tail, d_a, d_b;
+    // fused overlap-save path (ntaps <= FUSED_MAX_TAPS): 4096-point blocks, see fftfilt4096_kernel
+    static constexpr int FUSED_N = 4096, FUSED_MAX_TAPS = 2049;
+    bool fused = false;
+    int L = 0;                       // full-rate outputs per block, a multiple of the decimation
+    DevBuf d_tw4096, d_H4096, d_hist[2];
+    int hist_cur = 0;
 
     int install(const std::complex<float> *taps, size_t n)
     {
@@ -46,6 +52,35 @@ struct grhip_fft_filter_ccc : HandleBase {
             }
             H[k] = make_float2((float)acc.real(), (float)acc.imag());
         }
+        fused = ntaps <= FUSED_MAX_TAPS && ((FUSED_N - (ntaps - 1)) / decim) >= 1;
+        if (fused) {
+            L = ((FUSED_N - (ntaps - 1)) / decim) * decim;
+            std::vector<float2> tw4((size_t)FUSED_N), H4((size_t)FUSED_N);
+            for (int k = 0; k < FUSED_N; ++k) {
+                double ang = -2.0 * M_PI * (double)k / (double)FUSED_N;
+                tw4[k] = make_float2((float)cos(ang), (float)sin(ang));
+            }
+            const double sc = 1.0 / FUSED_N;
+            for (int k = 0; k < FUSED_N; ++k) {
+                std::complex<double> acc(0, 0);
+                for (int i = 0; i < ntaps; ++i) {
+                    double ang = -2.0 * M_PI * (double)(((long long)k * i) % FUSED_N) / (double)FUSED_N;
+                    acc += std::complex<double>(taps[i].real(), taps[i].imag()) * std::complex<double>(cos(ang), sin(ang));
+                }
+                H4[k] = make_float2((float)(acc.real() * sc), (float)(acc.imag() * sc));
+            }
+            const size_t hl = (size_t)(ntaps > 1 ? ntaps - 1 : 1);
+            int rc4 = d_tw4096.reserve(tw4.size() * sizeof(float2));
+            if (!rc4) rc4 = d_H4096.reserve(H4.size() * sizeof(float2));
+            if (!rc4) rc4 = d_hist[0].reserve(hl * sizeof(float2));
+            if (!rc4) rc4 = d_hist[1].reserve(hl * sizeof(float2));
+            if (rc4) return rc4;
+            GRHIP_HIP(hipMemcpy(d_tw4096.p, tw4.data(), tw4.size() * sizeof(float2), hipMemcpyHostToDevice));
+            GRHIP_HIP(hipMemcpy(d_H4096.p, H4.data(), H4.size() * sizeof(float2), hipMemcpyHostToDevice));
+            GRHIP_HIP(hipMemset(d_hist[0].p, 0, hl * sizeof(float2)));       // a fresh filter starts from silence
+            GRHIP_HIP(hipMemset(d_hist[1].p, 0, hl * sizeof(float2)));
+            hist_cur = 0;
+        }
         const size_t tail_items = (size_t)(ntaps > 1 ? ntaps - 1 : 1);
         int rc = d_twiddle.reserve(tw.size() * sizeof(float2));
         if (!rc) rc = d_xformed.reserve(H.size() * sizeof(float2));
@@ -56,7 +91,11 @@ struct grhip_fft_filter_ccc : HandleBase {
         GRHIP_HIP(hipMemset(d_tail.p, 0, tail_items * sizeof(float2)));                 // tail cleared (:69-71)
         return GRHIP_OK;
     }
-    void release_all() { d_twiddle.release(); d_xformed.release(); d_tail.release(); d_a.release(); d_b.release(); }
+    void release_all()
+    {
+        d_twiddle.release(); d_xformed.release(); d_tail.release(); d_a.release(); d_b.release();
+        d_tw4096.release(); d_H4096.release(); d_hist[0].release(); d_hist[1].release();
+    }
 };
 
 extern "C" {
@@ -116,6 +155,16 @@ int grhip_fft_filter_ccc_work_device(grhip_fft_filter_ccc *h, int noutput_items,
     if (noutput_items % h->nsamples)
         return fail(GRHIP_EINVAL, "noutput_items must be a multiple of nsamples (%d)", h->nsamples);
     const long long nin = (long long)noutput_items * h->decim;
+    if (h->fused) {
+        const float2 *hist = h->d_hist[h->hist_cur].as<float2>();
+        float2 *hist_new = h->d_hist[h->hist_cur ^ 1].as<float2>();
+        if ((rc = launch_fftfilt4096((const float2 *)d_in, nin, hist, h->ntaps, h->d_tw4096.as<float2>(),
+                                     h->d_H4096.as<float2>(), (float2 *)d_out, noutput_items, h->decim, h->L, st)))
+            return rc;
+        if ((rc = launch_fftfilt_hist((const float2 *)d_in, nin, hist, hist_new, h->ntaps - 1, st))) return rc;
+        h->hist_cur ^= 1;
+        return noutput_items;
+    }
     const long long nblk = nin / h->nsamples;
     const size_t bytes = (size_t)nblk * h->fftsize * sizeof(float2);
     if ((rc = h->d_a.reserve(bytes))) return rc;

@@ -26,6 +26,10 @@ struct PfbArgs {
 };
 int launch_pfb(const PfbArgs &a, hipStream_t st);
 
+// gr_fft_filter_ccc, fused overlap-save on 4096-point blocks (ntaps <= 2049)
+int launch_fftfilt4096(const float2 *in, long long nin, const float2 *hist, int ntaps, const float2 *twiddle,
+                       const float2 *H, float2 *out, long long nout, int decim, int L, hipStream_t st);
+int launch_fftfilt_hist(const float2 *in, long long nin, const float2 *hist_old, float2 *hist_new, int hlen, hipStream_t st);
 // gr_fft_filter_ccc helpers (overlap-add around launch_fft)
 int launch_fftfilt_pack(const float2 *in, float2 *blocks, int nsamples, int fftsize, long long nblk, hipStream_t st);
 int launch_fftfilt_mul(float2 *blocks, const float2 *xformed, int fftsize, long long nblk, hipStream_t st);

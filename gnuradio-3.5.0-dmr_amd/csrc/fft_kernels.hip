@@ -524,6 +524,122 @@ int launch_pfb(const PfbArgs &a, hipStream_t st)
 }
 
 // ===========================================================================
+// gr_fft_filter_ccc, fused: one workgroup = one 4096-sample block of overlap-SAVE fast
+// convolution.  Forward radix-16 FFT (first pass straight from HBM), spectrum times the
+// transformed taps in registers, inverse radix-16 FFT -- its first pass starts from the
+// registers the forward transform ended in, because "point q of lane t is index
+// t + 256 q" is both the output layout of a last Stockham pass and the input layout of a
+// first one -- and the last pass stores the valid, decimated outputs straight to HBM.
+// 8 B in + 8/D B out per sample, four LDS exchanges per block, no intermediate in HBM.
+// Block b produces full-rate outputs [bL, bL+L), L = 4096 - (ntaps-1) rounded down to a
+// multiple of the decimation, from inputs [bL-(ntaps-1), bL+L); inputs before the call come
+// from `hist` (the last ntaps-1 items of the previous call), inputs past nin read as zero.
+// The reference block is overlap-ADD with its own transform size; both are the same
+// convolution to within transform rounding (its FFTs are FFTW: unpinned anyway).
+// ===========================================================================
+template <bool FWD>
+__device__ __forceinline__ void fft4096_mid_passes(float2 (&v)[16], float2 *S, const float2 *__restrict__ twiddle, int t)
+{
+    auto pad = [](int i) { return i + (i >> 4); };
+    // pass 1 has been done by the caller's dft16; exchange, pass 2, exchange, pass 3
+#pragma unroll
+    for (int m = 0; m < 16; ++m) S[pad(16 * t + m)] = v[m];
+    __syncthreads();
+    {
+        const int k = t & 15;
+        float2 w[16];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) w[q] = tw<FWD>(twiddle, 16 * k * q);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = S[pad(t + 256 * q)];
+        __syncthreads();
+#pragma unroll
+        for (int q = 1; q < 16; ++q) v[q] = cmul2(v[q], w[q]);
+        dft16<FWD>(v);
+        const int j = (t - k) * 16 + k;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) S[pad(j + 16 * m)] = v[m];
+        __syncthreads();
+    }
+    {
+        float2 w[16];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) w[q] = tw<FWD>(twiddle, t * q);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = S[pad(t + 256 * q)];
+        __syncthreads();                    // S is reused by the next transform
+#pragma unroll
+        for (int q = 1; q < 16; ++q) v[q] = cmul2(v[q], w[q]);
+        dft16<FWD>(v);
+    }
+}
+
+__global__ void __launch_bounds__(256, 4)
+fftfilt4096_kernel(const float2 *__restrict__ in, long long nin, const float2 *__restrict__ hist, int ntaps,
+                   const float2 *__restrict__ twiddle, const float2 *__restrict__ H, float2 *__restrict__ out,
+                   long long nout, int decim, int L)
+{
+    constexpr int N = 4096;
+    __shared__ float2 S[N + N / 16];
+    const int t = threadIdx.x;
+    const long long b = blockIdx.x;
+    const long long base = b * L - (ntaps - 1);          // stream index of block position 0
+    float2 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const long long i = base + t + 256 * q;
+        float2 x = make_float2(0.f, 0.f);
+        if (i >= 0) { if (i < nin) x = in[i]; }
+        else x = hist[i + (ntaps - 1)];
+        v[q] = x;
+    }
+    dft16<true>(v);
+    fft4096_mid_passes<true>(v, S, twiddle, t);          // v[m] = X[t + 256 m]
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = cmul2(v[m], H[t + 256 * m]);
+    dft16<false>(v);                                     // inverse pass 1 on the same registers
+    fft4096_mid_passes<false>(v, S, twiddle, t);         // v[m] = z[t + 256 m]
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int j = t + 256 * m - (ntaps - 1);         // offset of this point inside the block's outputs
+        if (j >= 0 && j < L && (j % decim) == 0) {
+            const long long n = (b * L + j) / decim;
+            if (n < nout) out[n] = v[m];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+fftfilt_hist_kernel(const float2 *__restrict__ in, long long nin, const float2 *__restrict__ hist_old,
+                    float2 *__restrict__ hist_new, int hlen)
+{
+    // the last hlen items of (hist_old ++ in)
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= hlen) return;
+    const long long i = nin - hlen + j;                  // index into `in`, negative: still in the old history
+    hist_new[j] = i >= 0 ? in[i] : hist_old[i + hlen];
+}
+
+int launch_fftfilt4096(const float2 *in, long long nin, const float2 *hist, int ntaps, const float2 *twiddle,
+                       const float2 *H, float2 *out, long long nout, int decim, int L, hipStream_t st)
+{
+    if (nout <= 0) return GRHIP_OK;
+    const long long nblk = (nin + L - 1) / L;
+    hipLaunchKernelGGL(fftfilt4096_kernel, dim3((unsigned)nblk), dim3(256), 0, st, in, nin, hist, ntaps, twiddle, H, out,
+                       nout, decim, L);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+int launch_fftfilt_hist(const float2 *in, long long nin, const float2 *hist_old, float2 *hist_new, int hlen, hipStream_t st)
+{
+    if (hlen <= 0) return GRHIP_OK;
+    hipLaunchKernelGGL(fftfilt_hist_kernel, dim3((hlen + 255) / 256), dim3(256), 0, st, in, nin, hist_old, hist_new, hlen);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+// ===========================================================================
 // gr_fft_filter_ccc (filter/gri_fft_filter_ccc_generic.cc:121-169): the pieces around the
 // two transforms.  Blocks are independent except for the tail that block b adds into the
 // head of block b+1, so all blocks of a call are transformed in one batched launch and the

@@ -111,4 +111,18 @@ ns = blk.nsamples()
 n = ns * 65536
 x = torch.randn((n, 2), device=dev)
 y = torch.empty((n, 2), device=dev)
-report("fft_filter_ccc 256t D=1 (overlap-add, 512-pt)", timeit(lambda: blk.work_device(n, x, y, st), reps=20), n, 16)
+report("fft_filter_ccc 256t D=1 (fused overlap-save, 4096-pt blocks)", timeit(lambda: blk.work_device(n, x, y, st), reps=20), n, 16)
+# long filters: where fast convolution beats the direct form
+tl = (wl.lowpass_taps(2000, 0.05, 1.0) * np.exp(1j * 0.01 * np.arange(2000))).astype(np.complex64)
+blk = g.fft_filter_ccc(1, tl)
+ns = blk.nsamples()
+n = ns * (16_000_000 // ns)
+x = torch.randn((n + 2048, 2), device=dev)
+y = torch.empty((n, 2), device=dev)
+report("fft_filter_ccc 2000t D=1 (fused overlap-save)", timeit(lambda: blk.work_device(n, x, y, st), reps=20), n, 16)
+blk2 = g.fir_filter_ccc(1, tl)
+report("fir_filter_ccc 2000t D=1 (direct form, generic-order kernel: above the tiled kernel's 1024 taps)",
+       timeit(lambda: blk2.work_device(n, x, y, st), reps=5), n, 16)
+tm = tl[:1000]
+blk3 = g.fir_filter_ccc(1, tm)
+report("fir_filter_ccc 1000t D=1 (direct form, tiled kernel)", timeit(lambda: blk3.work_device(n, x, y, st), reps=10), n, 16)
