@@ -19,7 +19,6 @@ struct grhip_fft_filter_ccc : HandleBase {
     bool updated = false;
     DevBuf d_twiddle, d_xformed, d_tail, d_a, d_b;
     // fused overlap-save path (ntaps <= FUSED_MAX_TAPS): 4096-point blocks, see fftfilt4096_kernel
-    static constexpr int FUSED_N = 4096, FUSED_MAX_TAPS = 2049;
     bool fused = false;
     int L = 0;                       // full-rate outputs per block, a multiple of the decimation
     DevBuf d_tw4096, d_H4096, d_hist[2];
@@ -52,31 +51,13 @@ struct grhip_fft_filter_ccc : HandleBase {
             }
             H[k] = make_float2((float)acc.real(), (float)acc.imag());
         }
-        fused = ntaps <= FUSED_MAX_TAPS && ((FUSED_N - (ntaps - 1)) / decim) >= 1;
+        fused = ntaps <= OLS_MAX_TAPS && ((OLS_N - (ntaps - 1)) / decim) >= 1;
         if (fused) {
-            L = ((FUSED_N - (ntaps - 1)) / decim) * decim;
-            std::vector<float2> tw4((size_t)FUSED_N), H4((size_t)FUSED_N);
-            for (int k = 0; k < FUSED_N; ++k) {
-                double ang = -2.0 * M_PI * (double)k / (double)FUSED_N;
-                tw4[k] = make_float2((float)cos(ang), (float)sin(ang));
-            }
-            const double sc = 1.0 / FUSED_N;
-            for (int k = 0; k < FUSED_N; ++k) {
-                std::complex<double> acc(0, 0);
-                for (int i = 0; i < ntaps; ++i) {
-                    double ang = -2.0 * M_PI * (double)(((long long)k * i) % FUSED_N) / (double)FUSED_N;
-                    acc += std::complex<double>(taps[i].real(), taps[i].imag()) * std::complex<double>(cos(ang), sin(ang));
-                }
-                H4[k] = make_float2((float)(acc.real() * sc), (float)(acc.imag() * sc));
-            }
+            int rc4 = ols_build((const float *)taps, ntaps, decim, d_tw4096, d_H4096, &L);
             const size_t hl = (size_t)(ntaps > 1 ? ntaps - 1 : 1);
-            int rc4 = d_tw4096.reserve(tw4.size() * sizeof(float2));
-            if (!rc4) rc4 = d_H4096.reserve(H4.size() * sizeof(float2));
             if (!rc4) rc4 = d_hist[0].reserve(hl * sizeof(float2));
             if (!rc4) rc4 = d_hist[1].reserve(hl * sizeof(float2));
             if (rc4) return rc4;
-            GRHIP_HIP(hipMemcpy(d_tw4096.p, tw4.data(), tw4.size() * sizeof(float2), hipMemcpyHostToDevice));
-            GRHIP_HIP(hipMemcpy(d_H4096.p, H4.data(), H4.size() * sizeof(float2), hipMemcpyHostToDevice));
             GRHIP_HIP(hipMemset(d_hist[0].p, 0, hl * sizeof(float2)));       // a fresh filter starts from silence
             GRHIP_HIP(hipMemset(d_hist[1].p, 0, hl * sizeof(float2)));
             hist_cur = 0;

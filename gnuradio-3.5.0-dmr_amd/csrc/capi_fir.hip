@@ -3,6 +3,7 @@
 #include <cmath>
 #include <complex>
 
+#include "fft_kernels.h"
 #include "fir_kernels.h"
 #include "grhip_internal.h"
 #include "xlating_core.h"
@@ -107,6 +108,20 @@ int XlatingCore::build(int device)
             if (rc) return rc;
         }
     }
+    use_ols = false;
+    if (ntaps >= 48 && ntaps <= OLS_MAX_TAPS && (OLS_N - (ntaps - 1)) / decim >= 1) {
+        // convolution taps h[k] = ctaps[ntaps-1-k] (the composite FIR is set with gr_reverse(ctaps), .cc.t:80)
+        std::vector<float> h((size_t)ntaps * 2);
+        for (int k = 0; k < ntaps; ++k) {
+            h[2 * k] = ctaps[ntaps - 1 - k].real();
+            h[2 * k + 1] = ctaps[ntaps - 1 - k].imag();
+        }
+        rc = ols_build(h.data(), ntaps, decim, d_ols_tw, d_ols_H, &ols_L);
+        if (rc) return rc;
+        use_ols = true;
+    }
+    // same crossover as gr_fir_filter (see there); single-stream calls only, batched launches stay tiled
+    prefer_ols = use_ols && (!use_tiled || ntaps / decim > 120);
     reset();
     (void)device;
     return GRHIP_OK;
@@ -183,7 +198,7 @@ int XlatingCore::phase_before_pos(std::complex<float> *g)
 void XlatingCore::release()
 {
     d_taps_generic.release(); d_hp.release(); d_wtab.release(); d_stab.release(); d_vtab.release(); d_rot.release();
-    scratch_y.release(); sched.release();
+    scratch_y.release(); sched.release(); d_ols_tw.release(); d_ols_H.release();
 }
 
 // run the FIR + rotator (+ demod) for n_out outputs on device pointers.
@@ -196,13 +211,15 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
     if (n_out <= 0) return GRHIP_OK;
     const float2 *gtab = nullptr;
     const bool demod = d_demod != nullptr;
-    const bool direct = demod_is_direct(mode, demod);
+    const bool batched = !(n_streams == 1 && n_lo == 0);
+    const bool direct = demod_is_direct(mode, demod, batched);
     int rc = GRHIP_OK;
     if (!direct) {          // the direct demodulator epilogue needs no rotator phases
         rc = ensure_rot(n_out, &gtab);
         if (rc) return rc;
     }
-    if (mode == GRHIP_MODE_FAST && use_tiled) {
+    const bool ols_now = mode == GRHIP_MODE_FAST && prefer_ols && !batched;
+    if (mode == GRHIP_MODE_FAST && use_tiled && !ols_now) {
         FirTiledArgs a;
         memset(&a, 0, sizeof(a));
         a.x = d_in; a.x_stride = x_stride; a.n_in = n_in; a.n_lo = n_lo;
@@ -238,6 +255,25 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
             }
             if (y_last) GRHIP_HIP(hipMemcpy2DAsync(y_last, sizeof(float2), sy + n_out, ys * sizeof(float2), sizeof(float2),
                                                    n_streams, hipMemcpyDeviceToDevice, st));
+        }
+    } else if (ols_now) {
+        // overlap-save FIR (history in front of d_in = the engine's previous samples), rotator table
+        // multiply, stand-alone demodulator
+        float2 *y = d_y;
+        if (demod) {
+            rc = scratch_y.reserve((size_t)(n_out + 1) * sizeof(float2));
+            if (rc) return rc;
+            y = scratch_y.as<float2>() + 1;
+            GRHIP_HIP(hipMemcpyAsync(scratch_y.p, y_prev, sizeof(float2), hipMemcpyDeviceToDevice, st));
+        }
+        rc = launch_fftfilt4096(d_in + (ntaps - 1), n_out * decim, d_in, ntaps, d_ols_tw.as<float2>(),
+                                d_ols_H.as<float2>(), y, n_out, decim, ols_L, st);
+        if (!rc) rc = launch_rotate(y, gtab, n_out, st);
+        if (rc) return rc;
+        if (demod) {
+            rc = launch_quad_demod(scratch_y.as<float2>(), d_demod, n_out, gain, atan_tab, st);
+            if (rc) return rc;
+            GRHIP_HIP(hipMemcpyAsync(y_last, y + (n_out - 1), sizeof(float2), hipMemcpyDeviceToDevice, st));
         }
     } else {
         if (n_streams != 1 || n_lo != 0)
@@ -279,6 +315,11 @@ struct grhip_fir_filter : HandleBase {
     SchedBuf sched;
     int Tq = 0;
     bool use_tiled = false;
+    // FAST mode for the shapes the tiled kernel does not take (decimation other than 1/2/4, more
+    // than 1024 taps): the overlap-save engine of gr_fft_filter_ccc (fft_kernels.hip), any decimation
+    bool use_ols = false, prefer_ols = false;
+    int ols_L = 0;
+    DevBuf d_ols_tw, d_ols_H;
 
     int tw() const { return kind == FIR_CCC ? 2 : 1; }
     size_t in_item() const { return kind == FIR_FFF ? 4 : 8; }
@@ -305,13 +346,28 @@ struct grhip_fir_filter : HandleBase {
                 use_tiled = true;
             }
         }
+        use_ols = false;
+        if (kind != FIR_FFF && ntaps >= 48 && ntaps <= OLS_MAX_TAPS && (OLS_N - (ntaps - 1)) / decim >= 1) {
+            std::vector<float> ct((size_t)ntaps * 2);
+            for (int k = 0; k < ntaps; ++k) {
+                ct[2 * k] = kind == FIR_CCC ? taps[2 * k] : taps[k];
+                ct[2 * k + 1] = kind == FIR_CCC ? taps[2 * k + 1] : 0.f;
+            }
+            rc = ols_build(ct.data(), ntaps, decim, d_ols_tw, d_ols_H, &ols_L);
+            if (rc) return rc;
+            use_ols = true;
+        }
+        // Measured on MI355X (profiles/r01_blocks_bench.log): the tiled kernel runs at about
+        // 15000 / (taps per phase) Gsamples/s, the overlap-save engine at about 125 whatever the filter:
+        // fast convolution takes over above ~120 taps per phase.
+        prefer_ols = use_ols && (!use_tiled || ntaps / decim > 120);
         return GRHIP_OK;
     }
 
     int run(const void *d_in, void *d_out, long long n, int dec, hipStream_t st)
     {
         if (n <= 0) return GRHIP_OK;
-        if (mode == GRHIP_MODE_FAST && use_tiled && dec == decim && (kind != FIR_FFF || n >= 2)) {
+        if (mode == GRHIP_MODE_FAST && use_tiled && !prefer_ols && dec == decim && (kind != FIR_FFF || n >= 2)) {
             FirTiledArgs a;
             memset(&a, 0, sizeof(a));
             a.x = (const float2 *)d_in; a.n_in = (n - 1) * dec + ntaps;
@@ -327,6 +383,13 @@ struct grhip_fir_filter : HandleBase {
             if (rc || !(n & 1)) return rc;
             return launch_fir_generic(kind, d_taps_rev.as<float>(), ntaps, (const float *)d_in + (n - 1) * dec,
                                       (float *)d_out + (n - 1), 1, dec, nullptr, st);
+        }
+        if (mode == GRHIP_MODE_FAST && use_ols && dec == decim) {
+            // y[n] = sum_k taps[k] x[nD + ntaps-1-k]: the ntaps-1 history items in front of d_in are the
+            // engine's "previous call" samples, the rest is the stream
+            const float2 *x = (const float2 *)d_in;
+            return launch_fftfilt4096(x + (ntaps - 1), n * dec, x, ntaps, d_ols_tw.as<float2>(), d_ols_H.as<float2>(),
+                                      (float2 *)d_out, n, dec, ols_L, st);
         }
         return launch_fir_generic(kind, d_taps_rev.as<float>(), ntaps, d_in, d_out, n, dec, nullptr, st);
     }
@@ -351,7 +414,7 @@ int grhip_fir_filter_create(grhip_fir_filter **h, const char *kind, int decimati
     f->kind = k; f->decim = decimation; f->mode = default_mode();
     int rc = f->init_device(device);
     if (!rc) rc = f->install(std::vector<float>(taps, taps + ntaps * f->tw()));
-    if (rc) { f->d_taps_rev.release(); f->d_hp.release(); f->sched.release(); f->destroy_base(); delete f; return rc; }
+    if (rc) { f->d_taps_rev.release(); f->d_hp.release(); f->sched.release(); f->d_ols_tw.release(); f->d_ols_H.release(); f->destroy_base(); delete f; return rc; }
     *h = f;
     return GRHIP_OK;
 }
@@ -360,7 +423,7 @@ void grhip_fir_filter_destroy(grhip_fir_filter *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    h->d_taps_rev.release(); h->d_hp.release(); h->sched.release();
+    h->d_taps_rev.release(); h->d_hp.release(); h->sched.release(); h->d_ols_tw.release(); h->d_ols_H.release();
     h->destroy_base();
     delete h;
 }
@@ -779,7 +842,7 @@ int grhip_xlating_demod_run_captures_device(grhip_xlating_demod *h, int n_stream
     if (n_out <= 0) return GRHIP_OK;
     if (!(h->mode == GRHIP_MODE_FAST && h->core.use_tiled))
         return fail(GRHIP_EINVAL, "run_captures needs the tiled path (FAST mode, supported decimation)");
-    if (h->core.tab_start != 0 && !h->core.demod_is_direct(GRHIP_MODE_FAST, true))
+    if (h->core.tab_start != 0 && !h->core.demod_is_direct(GRHIP_MODE_FAST, true, true))
         return fail(GRHIP_EINVAL, "handle has streamed past its cached rotator table; use a fresh handle");
     const long long hist = h->core.ntaps > 0 ? h->core.ntaps - 1 : 0;
     const long long keep = h->core.pos;

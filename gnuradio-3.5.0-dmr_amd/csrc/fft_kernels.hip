@@ -1,6 +1,9 @@
 // fft_kernels.hip -- gfx950 kernels for gr_fft_vcc and gr_pfb_channelizer_ccf.
 #include "fft_kernels.h"
 
+#include <cmath>
+#include <vector>
+
 #include "device_math.h"
 #include "grhip_internal.h"
 
@@ -618,6 +621,37 @@ fftfilt_hist_kernel(const float2 *__restrict__ in, long long nin, const float2 *
     if (j >= hlen) return;
     const long long i = nin - hlen + j;                  // index into `in`, negative: still in the old history
     hist_new[j] = i >= 0 ? in[i] : hist_old[i + hlen];
+}
+
+int ols_build(const float *taps_cplx, int ntaps, int decim, DevBuf &d_tw, DevBuf &d_H, int *L)
+{
+    if (ntaps < 1 || ntaps > OLS_MAX_TAPS || decim < 1 || (OLS_N - (ntaps - 1)) / decim < 1)
+        return fail(GRHIP_EINVAL, "overlap-save engine: %d taps / decimation %d not supported", ntaps, decim);
+    *L = ((OLS_N - (ntaps - 1)) / decim) * decim;
+    std::vector<float2> tw((size_t)OLS_N), H((size_t)OLS_N);
+    std::vector<double> cs((size_t)OLS_N), sn((size_t)OLS_N);
+    for (int k = 0; k < OLS_N; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)OLS_N;
+        cs[k] = cos(ang); sn[k] = sin(ang);
+        tw[k] = make_float2((float)cs[k], (float)sn[k]);
+    }
+    const double sc = 1.0 / OLS_N;
+    for (int k = 0; k < OLS_N; ++k) {
+        double ar = 0, ai = 0;
+        for (int i = 0; i < ntaps; ++i) {
+            const int m = (int)(((long long)k * i) & (OLS_N - 1));
+            const double tr = taps_cplx[2 * i], ti = taps_cplx[2 * i + 1];
+            ar += tr * cs[m] - ti * sn[m];
+            ai += tr * sn[m] + ti * cs[m];
+        }
+        H[k] = make_float2((float)(ar * sc), (float)(ai * sc));
+    }
+    int rc = d_tw.reserve(tw.size() * sizeof(float2));
+    if (!rc) rc = d_H.reserve(H.size() * sizeof(float2));
+    if (rc) return rc;
+    GRHIP_HIP(hipMemcpy(d_tw.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    GRHIP_HIP(hipMemcpy(d_H.p, H.data(), H.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return GRHIP_OK;
 }
 
 int launch_fftfilt4096(const float2 *in, long long nin, const float2 *hist, int ntaps, const float2 *twiddle,

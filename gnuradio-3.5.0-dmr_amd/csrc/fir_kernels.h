@@ -60,6 +60,9 @@ int tiled_load_span();              // samples covered by one round of 16-byte l
 int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiledArgs &a,
                      int n_streams, hipStream_t st);
 
+// in-place rotator multiply with a phase table (gr_rotator.h:43)
+int launch_rotate(float2 *y, const float2 *gtab, long long n, hipStream_t st);
+
 // standalone quadrature demod: in has 1 history item in front
 int launch_quad_demod(const float2 *in, float *out, long long n_out, float gain,
                       const float *atan_tab, hipStream_t st);

@@ -146,6 +146,25 @@ quad_demod_kernel(const float2 *__restrict__ in, float *__restrict__ out, long l
         if (i0 + k < n_out) out[i0 + k] = quad_demod_one(v[k + 1], v[k], gain, tab);
 }
 
+// y[n] = y[n] * phase[n] with the reference's unfused complex product (gr_rotator.h:43)
+__global__ void __launch_bounds__(256)
+rotate_kernel(float2 *__restrict__ y, const float2 *__restrict__ gtab, long long n)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = cmul_ref(y[i], gtab[i]);
+}
+
+int launch_rotate(float2 *y, const float2 *gtab, long long n, hipStream_t st)
+{
+    if (n <= 0) return GRHIP_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(rotate_kernel, dim3((unsigned)blocks), dim3(256), 0, st, y, gtab, n);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
 int launch_quad_demod(const float2 *in, float *out, long long n_out, float gain, const float *atan_tab,
                       hipStream_t st)
 {

@@ -32,6 +32,11 @@ struct XlatingCore {
     DevBuf d_hp, d_wtab, d_stab, d_vtab;        // tiled kernel operands
     int Tq = 0;
     bool use_tiled = false, premix = false;
+    // FAST mode for the shapes the tiled kernel does not take (other decimations, long prototypes):
+    // overlap-save engine (fft_kernels.hip) + rotator table multiply
+    bool use_ols = false, prefer_ols = false;
+    int ols_L = 0;
+    DevBuf d_ols_tw, d_ols_H;
     DevBuf scratch_y;
     SchedBuf sched;                             // tile queue of the tiled kernel (one launch at a time per handle)
 
@@ -69,9 +74,11 @@ struct XlatingCore {
     int ensure_rot(long long n, const float2 **gtab);
     int phase_before_pos(std::complex<float> *g);
     // fused demodulator on the pre-mixed accumulators (EPI_DEMOD): FAST mode, real prototype taps
-    bool demod_is_direct(int mode, bool demod) const
+    // (single-stream calls of a long filter go through the overlap-save engine instead; batched
+    // launches -- several streams, or history supplied by range check -- always take the tiled kernel)
+    bool demod_is_direct(int mode, bool demod, bool batched = false) const
     {
-        return demod && mode == GRHIP_MODE_FAST && use_tiled && premix;
+        return demod && mode == GRHIP_MODE_FAST && use_tiled && premix && (batched || !prefer_ols);
     }
     // d_in item 0 = input[0] of output 0 (oldest history item); items with index
     // < n_lo or >= n_in read as zero.  n_streams > 1: stream s at d_in + s*x_stride,

@@ -44,7 +44,8 @@ def test_fir_generic_mode_bit_exact(gpu, po, kind, ntaps, decim):
 
 
 @pytest.mark.parametrize("kind", ["ccf", "ccc"])
-@pytest.mark.parametrize("ntaps,decim", [(1, 1), (3, 1), (64, 1), (65, 2), (256, 4), (255, 4), (256, 1), (31, 8), (40, 3)])
+@pytest.mark.parametrize("ntaps,decim", [(1, 1), (3, 1), (64, 1), (65, 2), (256, 4), (255, 4), (256, 1), (31, 8), (40, 3),
+                                         (200, 3), (1500, 1), (2049, 5), (600, 8)])    # last four: overlap-save engine
 def test_fir_fast_mode_tolerance(gpu, po, kind, ntaps, decim):
     rng = np.random.default_rng(1000 + ntaps * 10 + decim)
     n = 5003           # not a multiple of the tile: exercises the ragged tail
@@ -146,6 +147,33 @@ def test_xlating_generic_bit_exact_and_rotator_carry(gpu, po, wl):
     blk.reset()
     got = gpu.run_sync_block(blk, x, chunk=1000)
     assert bits_equal(got, ref)
+
+
+@pytest.mark.parametrize("decim,ntaps", [(10, 256), (5, 1200), (25, 400)])
+def test_xlating_fast_other_decimations(gpu, po, wl, decim, ntaps):
+    """decimations the tiled kernel does not take (and prototypes beyond its 1024 taps): FAST mode goes
+    through the overlap-save engine + rotator table (+ stand-alone demodulator), chunked calls included"""
+    c = wl.CFG2
+    n = 300_000
+    x = wl.fsk4_capture(n, stream_id=31)
+    proto = wl.lowpass_taps(ntaps, 0.02, 1.0).astype(np.complex64)
+    nout = n // decim
+    xin = wl.with_history(x[: nout * decim], ntaps - 1)
+    ref = po.Xlating(decim, proto, c["center_freq"], c["fs"]).work(xin, nout)
+    blk = gpu.freq_xlating_fir_filter_ccc(decim, proto, c["center_freq"], c["fs"])
+    blk.set_mode(gpu.MODE_FAST)
+    got = blk.work(nout, xin)
+    assert rel_err_max(got, ref) <= TOL
+    blk.reset()
+    got2 = gpu.run_sync_block(blk, x[: nout * decim], chunk=1000)
+    assert rel_err_max(got2, ref) <= TOL
+    # fused handle: same path + demodulator, carry across calls
+    gain = 2.0
+    dref = po.chain_xlating_demod(decim, proto, c["center_freq"], c["fs"], gain, x[: nout * decim])
+    fz = gpu.xlating_demod(decim, proto, c["center_freq"], c["fs"], gain)
+    d = gpu.run_sync_block(fz, x[: nout * decim], chunk=7000)
+    ok, worst = demod_close(d, dref, skip=max(64, ntaps // decim + 1), gain=gain)
+    assert ok, worst
 
 
 @pytest.mark.parametrize("complex_proto", [False, True])

@@ -121,8 +121,21 @@ x = torch.randn((n + 2048, 2), device=dev)
 y = torch.empty((n, 2), device=dev)
 report("fft_filter_ccc 2000t D=1 (fused overlap-save)", timeit(lambda: blk.work_device(n, x, y, st), reps=20), n, 16)
 blk2 = g.fir_filter_ccc(1, tl)
-report("fir_filter_ccc 2000t D=1 (direct form, generic-order kernel: above the tiled kernel's 1024 taps)",
+report("fir_filter_ccc 2000t D=1 FAST (dispatches to the overlap-save engine)",
        timeit(lambda: blk2.work_device(n, x, y, st), reps=5), n, 16)
 tm = tl[:1000]
 blk3 = g.fir_filter_ccc(1, tm)
-report("fir_filter_ccc 1000t D=1 (direct form, tiled kernel)", timeit(lambda: blk3.work_device(n, x, y, st), reps=10), n, 16)
+report("fir_filter_ccc 1000t D=1 FAST (dispatches to the overlap-save engine)", timeit(lambda: blk3.work_device(n, x, y, st), reps=10), n, 16)
+blk4 = g.fir_filter_ccf(1, wl.lowpass_taps(256, 0.1, 1.0))
+report("fir_filter_ccf 256t D=1 FAST (overlap-save engine: 256 taps per phase)", timeit(lambda: blk4.work_device(n, x, y, st), reps=10), n, 16)
+blk5 = g.fir_filter_ccf(1, wl.lowpass_taps(128, 0.1, 1.0))
+report("fir_filter_ccf 128t D=1 FAST (tiled kernel)", timeit(lambda: blk5.work_device(n, x, y, st), reps=10), n, 16)
+
+# freq_xlating_fir_filter_ccc at a decimation the tiled kernel does not take: overlap-save engine + rotator
+n = 160_000_000
+x = torch.randn((n + 512, 2), device=dev)
+y = torch.empty((n // 20, 2), device=dev)
+blk = g.freq_xlating_fir_filter_ccc(20, wl.lowpass_taps(400, 0.02, 1.0).astype(np.complex64), c["center_freq"], c["fs"])
+def run_xl20():
+    blk.reset(); blk.work_device(n // 20, x, y, st)
+report("freq_xlating_fir_filter_ccc 400t D=20 (overlap-save engine)", timeit(run_xl20, reps=10), n, 8.4)
