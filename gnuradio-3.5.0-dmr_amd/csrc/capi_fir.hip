@@ -266,7 +266,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
             y = scratch_y.as<float2>() + 1;
             GRHIP_HIP(hipMemcpyAsync(scratch_y.p, y_prev, sizeof(float2), hipMemcpyDeviceToDevice, st));
         }
-        rc = launch_fftfilt4096(d_in + (ntaps - 1), n_out * decim, d_in, ntaps, d_ols_tw.as<float2>(),
+        rc = launch_fftfilt4096(d_in + (ntaps - 1), (n_out - 1) * decim + 1, d_in, ntaps, d_ols_tw.as<float2>(),
                                 d_ols_H.as<float2>(), y, n_out, decim, ols_L, st);
         if (!rc) rc = launch_rotate(y, gtab, n_out, st);
         if (rc) return rc;
@@ -388,8 +388,9 @@ struct grhip_fir_filter : HandleBase {
             // y[n] = sum_k taps[k] x[nD + ntaps-1-k]: the ntaps-1 history items in front of d_in are the
             // engine's "previous call" samples, the rest is the stream
             const float2 *x = (const float2 *)d_in;
-            return launch_fftfilt4096(x + (ntaps - 1), n * dec, x, ntaps, d_ols_tw.as<float2>(), d_ols_H.as<float2>(),
-                                      (float2 *)d_out, n, dec, ols_L, st);
+            // (the scheduler guarantees (n-1)*dec + ntaps items: nothing past the last needed sample is read)
+            return launch_fftfilt4096(x + (ntaps - 1), (n - 1) * dec + 1, x, ntaps, d_ols_tw.as<float2>(),
+                                      d_ols_H.as<float2>(), (float2 *)d_out, n, dec, ols_L, st);
         }
         return launch_fir_generic(kind, d_taps_rev.as<float>(), ntaps, d_in, d_out, n, dec, nullptr, st);
     }

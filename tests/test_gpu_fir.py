@@ -167,6 +167,11 @@ def test_xlating_fast_other_decimations(gpu, po, wl, decim, ntaps):
     blk.reset()
     got2 = gpu.run_sync_block(blk, x[: nout * decim], chunk=1000)
     assert rel_err_max(got2, ref) <= TOL
+    # exactly the items the scheduler guarantees ((n-1)*decim + ntaps) followed by NaNs: nothing past them is used
+    blk.reset()
+    guarded = np.concatenate([xin[: (nout - 1) * decim + ntaps], np.full(decim + 8, np.nan + 1j * np.nan, np.complex64)])
+    got3 = blk.work(nout, guarded)
+    assert np.isfinite(got3).all() and rel_err_max(got3, ref) <= TOL
     # fused handle: same path + demodulator, carry across calls
     gain = 2.0
     dref = po.chain_xlating_demod(decim, proto, c["center_freq"], c["fs"], gain, x[: nout * decim])
@@ -454,3 +459,23 @@ def test_fir_random_shapes_fast_mode(gpu, po):
         assert got.shape == ref.shape, (kind, ntaps, decim, n)
         err = np.abs(got - ref).max()
         assert err <= TOL * max(np.abs(ref).max(), 1e-3 * bound), (kind, ntaps, decim, n, err)
+
+
+@pytest.mark.parametrize("kind,ntaps,decim", [("ccf", 300, 1), ("ccc", 200, 3), ("ccf", 256, 4), ("ccc", 64, 2)])
+def test_fir_reads_nothing_past_the_guaranteed_items(gpu, po, kind, ntaps, decim):
+    """the scheduler guarantees (n-1)*decim + ntaps input items (gr_sync_decimator.cc:46-50); whatever
+    follows them (NaNs here) must not reach the outputs -- tiled kernel and overlap-save engine alike"""
+    rng = np.random.default_rng(ntaps)
+    n = 5000
+    need = (n - 1) * decim + ntaps
+    x = np.concatenate([_rand_c(rng, need), np.full(decim + 64, np.nan + 1j * np.nan, np.complex64)])
+    if kind == "ccf":
+        taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+        blk, ref = gpu.fir_filter_ccf(decim, taps), po.fir_ccf(taps, x[:need], n, decim)
+    else:
+        taps = _rand_c(rng, ntaps)
+        blk, ref = gpu.fir_filter_ccc(decim, taps), po.fir_ccc(taps, x[:need], n, decim)
+    blk.set_mode(gpu.MODE_FAST)
+    got = blk.work(n, x)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= TOL * np.abs(ref).max() * 4
