@@ -347,7 +347,7 @@ struct grhip_fir_filter : HandleBase {
             }
         }
         use_ols = false;
-        if (kind != FIR_FFF && ntaps >= 48 && ntaps <= OLS_MAX_TAPS && (OLS_N - (ntaps - 1)) / decim >= 1) {
+        if (ntaps >= 48 && ntaps <= OLS_MAX_TAPS && (OLS_N - (ntaps - 1)) / decim >= 1) {
             std::vector<float> ct((size_t)ntaps * 2);
             for (int k = 0; k < ntaps; ++k) {
                 ct[2 * k] = kind == FIR_CCC ? taps[2 * k] : taps[k];
@@ -360,7 +360,8 @@ struct grhip_fir_filter : HandleBase {
         // Measured on MI355X (profiles/r01_blocks_bench.log): the tiled kernel runs at about
         // 15000 / (taps per phase) Gsamples/s, the overlap-save engine at about 125 whatever the filter:
         // fast convolution takes over above ~120 taps per phase.
-        prefer_ols = use_ols && (!use_tiled || ntaps / decim > 120);
+        // (float data: the engine only where the float-pair mode of the tiled kernel does not reach)
+        prefer_ols = use_ols && (!use_tiled || (kind != FIR_FFF && ntaps / decim > 120));
         return GRHIP_OK;
     }
 
@@ -384,9 +385,14 @@ struct grhip_fir_filter : HandleBase {
             return launch_fir_generic(kind, d_taps_rev.as<float>(), ntaps, (const float *)d_in + (n - 1) * dec,
                                       (float *)d_out + (n - 1), 1, dec, nullptr, st);
         }
-        if (mode == GRHIP_MODE_FAST && use_ols && dec == decim) {
+        if (mode == GRHIP_MODE_FAST && use_ols && (prefer_ols || !use_tiled) && dec == decim) {
             // y[n] = sum_k taps[k] x[nD + ntaps-1-k]: the ntaps-1 history items in front of d_in are the
             // engine's "previous call" samples, the rest is the stream
+            if (kind == FIR_FFF) {
+                const float *xf = (const float *)d_in;
+                return launch_fftfilt4096_real(xf + (ntaps - 1), (n - 1) * dec + 1, xf, ntaps, d_ols_tw.as<float2>(),
+                                               d_ols_H.as<float2>(), (float *)d_out, n, dec, ols_L, st);
+            }
             const float2 *x = (const float2 *)d_in;
             // (the scheduler guarantees (n-1)*dec + ntaps items: nothing past the last needed sample is read)
             return launch_fftfilt4096(x + (ntaps - 1), (n - 1) * dec + 1, x, ntaps, d_ols_tw.as<float2>(),

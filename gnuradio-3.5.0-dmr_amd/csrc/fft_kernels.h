@@ -34,6 +34,8 @@ constexpr int OLS_N = 4096, OLS_MAX_TAPS = 2049;
 int ols_build(const float *taps_cplx, int ntaps, int decim, DevBuf &d_tw, DevBuf &d_H, int *L);
 int launch_fftfilt4096(const float2 *in, long long nin, const float2 *hist, int ntaps, const float2 *twiddle,
                        const float2 *H, float2 *out, long long nout, int decim, int L, hipStream_t st);
+int launch_fftfilt4096_real(const float *in, long long nin, const float *hist, int ntaps, const float2 *twiddle,
+                            const float2 *H, float *out, long long nout, int decim, int L, hipStream_t st);
 int launch_fftfilt_hist(const float2 *in, long long nin, const float2 *hist_old, float2 *hist_new, int hlen, hipStream_t st);
 // gr_fft_filter_ccc helpers (overlap-add around launch_fft)
 int launch_fftfilt_pack(const float2 *in, float2 *blocks, int nsamples, int fftsize, long long nblk, hipStream_t st);

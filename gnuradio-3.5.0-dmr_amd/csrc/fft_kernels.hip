@@ -577,9 +577,12 @@ __device__ __forceinline__ void fft4096_mid_passes(float2 (&v)[16], float2 *S, c
     }
 }
 
+// REAL: float items in and out (gr_fir_fff shapes the tiled kernel does not take): the imaginary
+// half of the transform idles, still far ahead of the one-output-per-lane generic kernel.
+template <bool REAL>
 __global__ void __launch_bounds__(256, 4)
-fftfilt4096_kernel(const float2 *__restrict__ in, long long nin, const float2 *__restrict__ hist, int ntaps,
-                   const float2 *__restrict__ twiddle, const float2 *__restrict__ H, float2 *__restrict__ out,
+fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__restrict__ hist_v, int ntaps,
+                   const float2 *__restrict__ twiddle, const float2 *__restrict__ H, void *__restrict__ out_v,
                    long long nout, int decim, int L)
 {
     constexpr int N = 4096;
@@ -592,8 +595,15 @@ fftfilt4096_kernel(const float2 *__restrict__ in, long long nin, const float2 *_
     for (int q = 0; q < 16; ++q) {
         const long long i = base + t + 256 * q;
         float2 x = make_float2(0.f, 0.f);
-        if (i >= 0) { if (i < nin) x = in[i]; }
-        else x = hist[i + (ntaps - 1)];
+        if (REAL) {
+            const float *in = (const float *)in_v, *hist = (const float *)hist_v;
+            if (i >= 0) { if (i < nin) x.x = in[i]; }
+            else x.x = hist[i + (ntaps - 1)];
+        } else {
+            const float2 *in = (const float2 *)in_v, *hist = (const float2 *)hist_v;
+            if (i >= 0) { if (i < nin) x = in[i]; }
+            else x = hist[i + (ntaps - 1)];
+        }
         v[q] = x;
     }
     dft16<true>(v);
@@ -607,7 +617,10 @@ fftfilt4096_kernel(const float2 *__restrict__ in, long long nin, const float2 *_
         const int j = t + 256 * m - (ntaps - 1);         // offset of this point inside the block's outputs
         if (j >= 0 && j < L && (j % decim) == 0) {
             const long long n = (b * L + j) / decim;
-            if (n < nout) out[n] = v[m];
+            if (n < nout) {
+                if (REAL) ((float *)out_v)[n] = v[m].x;
+                else ((float2 *)out_v)[n] = v[m];
+            }
         }
     }
 }
@@ -659,8 +672,19 @@ int launch_fftfilt4096(const float2 *in, long long nin, const float2 *hist, int 
 {
     if (nout <= 0) return GRHIP_OK;
     const long long nblk = (nin + L - 1) / L;
-    hipLaunchKernelGGL(fftfilt4096_kernel, dim3((unsigned)nblk), dim3(256), 0, st, in, nin, hist, ntaps, twiddle, H, out,
-                       nout, decim, L);
+    hipLaunchKernelGGL(fftfilt4096_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, (const void *)in, nin,
+                       (const void *)hist, ntaps, twiddle, H, (void *)out, nout, decim, L);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+int launch_fftfilt4096_real(const float *in, long long nin, const float *hist, int ntaps, const float2 *twiddle,
+                            const float2 *H, float *out, long long nout, int decim, int L, hipStream_t st)
+{
+    if (nout <= 0) return GRHIP_OK;
+    const long long nblk = (nin + L - 1) / L;
+    hipLaunchKernelGGL(fftfilt4096_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, (const void *)in, nin,
+                       (const void *)hist, ntaps, twiddle, H, (void *)out, nout, decim, L);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
 }
