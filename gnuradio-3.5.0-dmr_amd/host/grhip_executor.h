@@ -22,8 +22,14 @@ class grhip_linear_flowgraph {
     struct edge { std::vector<unsigned char> data; size_t item = 1; size_t rd = 0; };   // rd in items
     std::vector<gr_block_sptr> d_blocks;
     int d_max_noutput;
+    bool d_drain_tail;
 public:
-    explicit grhip_linear_flowgraph(int max_noutput = 1 << 20) : d_max_noutput(max_noutput) {}
+    // drain_tail = true: once the source is exhausted, what is left in front of a block is pushed through
+    // item by item so that every output of a finite test vector is produced.  false: the reference's
+    // behaviour -- a block whose forecast for one output_multiple cannot be met any more is done
+    // (runtime/gr_block_executor.cc:335-348); needed for blocks that insist on whole output multiples.
+    explicit grhip_linear_flowgraph(int max_noutput = 1 << 20, bool drain_tail = true)
+        : d_max_noutput(max_noutput), d_drain_tail(drain_tail) {}
     void connect(gr_block_sptr b) { d_blocks.push_back(b); }
 
     // runs `input` (n_in items of the first block's input size) through the chain,
@@ -59,7 +65,7 @@ public:
                         if ((size_t)req[0] <= avail) break;
                         if (nout <= mult) {
                             // below one output_multiple: allowed only when upstream is finished
-                            if (!upstream_done[i] || mult == 1) { nout = 0; break; }
+                            if (!upstream_done[i] || mult == 1 || !d_drain_tail) { nout = 0; break; }
                             mult = 1;                      // drain the tail item by item
                             nout = std::max(1, nout / 2);
                             continue;

@@ -55,9 +55,28 @@ static int test_errors()
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::cerr << "usage: host_chain_test <dir> <chain|errors>\n"; return 2; }
+    if (argc < 3) { std::cerr << "usage: host_chain_test <dir> <chain|errors|widened>\n"; return 2; }
     std::string dir = argv[1], mode = argv[2];
     if (mode == "errors") return test_errors();
+    if (mode == "widened") {
+        // SURVEY 8f blocks through the block interface: fft_filter_ccc (output multiple nsamples) and
+        // pager_slicer_fb -> unpack_k_bits_bb (gr_sync_interpolator), reference scheduler semantics for the tail
+        std::vector<gr_complex> x = slurp<gr_complex>(dir + "/x.c64");
+        std::vector<gr_complex> taps = slurp<gr_complex>(dir + "/taps.c64");
+        std::vector<float> soft = slurp<float>(dir + "/soft.f32");
+        gr_block_sptr ff = grhip_make_fft_filter_ccc(2, taps);
+        grhip_linear_flowgraph g1(1 << 16, false); g1.connect(ff);
+        dump(dir + "/fftfilt.c64", g1.run(x.data(), x.size()));
+        grhip_pager_slicer_fb_sptr ps = grhip_make_pager_slicer_fb(0.002f);
+        gr_block_sptr up = grhip_make_unpack_k_bits_bb(2);
+        grhip_linear_flowgraph g2(1 << 16, false); g2.connect(ps); g2.connect(up);
+        dump(dir + "/dibits.u8", g2.run(soft.data(), soft.size()));
+        std::vector<float> dc(1, ps->dc_offset());
+        std::vector<unsigned char> dcb((unsigned char *)dc.data(), (unsigned char *)dc.data() + 4);
+        dump(dir + "/dc.f32", dcb);
+        std::cout << "widened ok\n";
+        return 0;
+    }
 
     std::vector<gr_complex> x = slurp<gr_complex>(dir + "/x.c64");
     std::vector<gr_complex> taps = slurp<gr_complex>(dir + "/taps.c64");

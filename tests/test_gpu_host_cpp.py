@@ -58,3 +58,28 @@ def test_cpp_chain_through_block_interface(exe, tmp_path, po, wl):
     assert bits_equal(soft, soft_ref[:len(soft)])
     out_ref = po.CorrelateAccessCode(wl.access_code_string(), c4["threshold"]).work(po.binary_slicer_fb(soft))
     assert np.array_equal(bits, out_ref)
+
+
+def test_cpp_widened_blocks_through_block_interface(exe, tmp_path, po, wl):
+    """fft_filter_ccc (output multiple nsamples, history 1) and pager_slicer_fb -> unpack_k_bits_bb
+    (gr_sync_interpolator) as C++ blocks under the executor with the reference's tail semantics"""
+    rng = np.random.default_rng(12)
+    n = 200_000
+    x = wl.fsk4_capture(n, stream_id=13)
+    taps = (wl.lowpass_taps(300, 0.1, 1.0) * np.exp(1j * 0.02 * np.arange(300))).astype(np.complex64)
+    soft = (rng.integers(0, 4, 70_001) * 2.0 - 3.0 + 0.4 + 0.3 * rng.standard_normal(70_001)).astype(np.float32)
+    x.tofile(tmp_path / "x.c64"); taps.tofile(tmp_path / "taps.c64"); soft.tofile(tmp_path / "soft.f32")
+    r = subprocess.run([exe, str(tmp_path), "widened"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    y = np.fromfile(tmp_path / "fftfilt.c64", np.complex64)
+    ref_blk = po.FftFilterCcc(2, taps)
+    ns = ref_blk.nsamples
+    # whole output multiples only; the tail that cannot fill one is left in the buffer, as in the reference
+    assert len(y) % ns == 0 and 0 <= n // 2 - len(y) < ns
+    ref = ref_blk.filter(len(y), x)
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()
+    bits = np.fromfile(tmp_path / "dibits.u8", np.uint8)
+    o = po.PagerSlicer(0.002)
+    sym = o.work(soft)
+    assert np.array_equal(bits, po.unpack_k_bits_bb(2, sym))
+    assert np.fromfile(tmp_path / "dc.f32", np.float32)[0].tobytes() == o.dc_offset().tobytes()
