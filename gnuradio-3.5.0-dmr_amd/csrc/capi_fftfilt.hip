@@ -20,7 +20,7 @@ struct grhip_fft_filter_ccc : HandleBase {
     DevBuf d_twiddle, d_xformed, d_tail, d_a, d_b;
     // fused overlap-save path (ntaps <= FUSED_MAX_TAPS): 4096-point blocks, see fftfilt4096_kernel
     bool fused = false;
-    int L = 0;                       // full-rate outputs per block, a multiple of the decimation
+    int L = 0, fold = 0;             // full-rate outputs per block (a multiple of the decimation); folded inverse
     DevBuf d_tw4096, d_H4096, d_hist[2];
     int hist_cur = 0;
 
@@ -53,7 +53,7 @@ struct grhip_fft_filter_ccc : HandleBase {
         }
         fused = ntaps <= OLS_MAX_TAPS && ((OLS_N - (ntaps - 1)) / decim) >= 1;
         if (fused) {
-            int rc4 = ols_build((const float *)taps, ntaps, decim, d_tw4096, d_H4096, &L);
+            int rc4 = ols_build((const float *)taps, ntaps, decim, d_tw4096, d_H4096, &L, &fold);
             const size_t hl = (size_t)(ntaps > 1 ? ntaps - 1 : 1);
             if (!rc4) rc4 = d_hist[0].reserve(hl * sizeof(float2));
             if (!rc4) rc4 = d_hist[1].reserve(hl * sizeof(float2));
@@ -140,7 +140,7 @@ int grhip_fft_filter_ccc_work_device(grhip_fft_filter_ccc *h, int noutput_items,
         const float2 *hist = h->d_hist[h->hist_cur].as<float2>();
         float2 *hist_new = h->d_hist[h->hist_cur ^ 1].as<float2>();
         if ((rc = launch_fftfilt4096((const float2 *)d_in, nin, hist, h->ntaps, h->d_tw4096.as<float2>(),
-                                     h->d_H4096.as<float2>(), (float2 *)d_out, noutput_items, h->decim, h->L, st)))
+                                     h->d_H4096.as<float2>(), (float2 *)d_out, noutput_items, h->decim, h->L, h->fold, st)))
             return rc;
         if ((rc = launch_fftfilt_hist((const float2 *)d_in, nin, hist, hist_new, h->ntaps - 1, st))) return rc;
         h->hist_cur ^= 1;

@@ -116,7 +116,7 @@ int XlatingCore::build(int device)
             h[2 * k] = ctaps[ntaps - 1 - k].real();
             h[2 * k + 1] = ctaps[ntaps - 1 - k].imag();
         }
-        rc = ols_build(h.data(), ntaps, decim, d_ols_tw, d_ols_H, &ols_L);
+        rc = ols_build(h.data(), ntaps, decim, d_ols_tw, d_ols_H, &ols_L, &ols_fold);
         if (rc) return rc;
         use_ols = true;
     }
@@ -267,7 +267,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
             GRHIP_HIP(hipMemcpyAsync(scratch_y.p, y_prev, sizeof(float2), hipMemcpyDeviceToDevice, st));
         }
         rc = launch_fftfilt4096(d_in + (ntaps - 1), (n_out - 1) * decim + 1, d_in, ntaps, d_ols_tw.as<float2>(),
-                                d_ols_H.as<float2>(), y, n_out, decim, ols_L, st);
+                                d_ols_H.as<float2>(), y, n_out, decim, ols_L, ols_fold, st);
         if (!rc) rc = launch_rotate(y, gtab, n_out, st);
         if (rc) return rc;
         if (demod) {
@@ -318,7 +318,7 @@ struct grhip_fir_filter : HandleBase {
     // FAST mode for the shapes the tiled kernel does not take (decimation other than 1/2/4, more
     // than 1024 taps): the overlap-save engine of gr_fft_filter_ccc (fft_kernels.hip), any decimation
     bool use_ols = false, prefer_ols = false;
-    int ols_L = 0;
+    int ols_L = 0, ols_fold = 0;
     DevBuf d_ols_tw, d_ols_H;
 
     int tw() const { return kind == FIR_CCC ? 2 : 1; }
@@ -353,7 +353,7 @@ struct grhip_fir_filter : HandleBase {
                 ct[2 * k] = kind == FIR_CCC ? taps[2 * k] : taps[k];
                 ct[2 * k + 1] = kind == FIR_CCC ? taps[2 * k + 1] : 0.f;
             }
-            rc = ols_build(ct.data(), ntaps, decim, d_ols_tw, d_ols_H, &ols_L);
+            rc = ols_build(ct.data(), ntaps, decim, d_ols_tw, d_ols_H, &ols_L, &ols_fold);
             if (rc) return rc;
             use_ols = true;
         }
@@ -391,12 +391,12 @@ struct grhip_fir_filter : HandleBase {
             if (kind == FIR_FFF) {
                 const float *xf = (const float *)d_in;
                 return launch_fftfilt4096_real(xf + (ntaps - 1), (n - 1) * dec + 1, xf, ntaps, d_ols_tw.as<float2>(),
-                                               d_ols_H.as<float2>(), (float *)d_out, n, dec, ols_L, st);
+                                               d_ols_H.as<float2>(), (float *)d_out, n, dec, ols_L, ols_fold, st);
             }
             const float2 *x = (const float2 *)d_in;
             // (the scheduler guarantees (n-1)*dec + ntaps items: nothing past the last needed sample is read)
             return launch_fftfilt4096(x + (ntaps - 1), (n - 1) * dec + 1, x, ntaps, d_ols_tw.as<float2>(),
-                                      d_ols_H.as<float2>(), (float2 *)d_out, n, dec, ols_L, st);
+                                      d_ols_H.as<float2>(), (float2 *)d_out, n, dec, ols_L, ols_fold, st);
         }
         return launch_fir_generic(kind, d_taps_rev.as<float>(), ntaps, d_in, d_out, n, dec, nullptr, st);
     }

@@ -579,7 +579,10 @@ __device__ __forceinline__ void fft4096_mid_passes(float2 (&v)[16], float2 *S, c
 
 // REAL: float items in and out (gr_fir_fff shapes the tiled kernel does not take): the imaginary
 // half of the transform idles, still far ahead of the one-output-per-lane generic kernel.
-template <bool REAL>
+// FOLD = log2(decimation) for decimations 2, 4, 8, 16 (0: any decimation, full-size inverse).  Keeping every
+// D-th output of the block, starting at its first valid one (offset ntaps-1: that shift is folded into H on the
+// host), is the (4096/D)-point inverse transform of the spectrum folded D times: the inverse costs 1/D-th.
+template <bool REAL, int FOLD>
 __global__ void __launch_bounds__(256, 4)
 fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__restrict__ hist_v, int ntaps,
                    const float2 *__restrict__ twiddle, const float2 *__restrict__ H, void *__restrict__ out_v,
@@ -610,6 +613,62 @@ fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__r
     fft4096_mid_passes<true>(v, S, twiddle, t);          // v[m] = X[t + 256 m]
 #pragma unroll
     for (int m = 0; m < 16; ++m) v[m] = cmul2(v[m], H[t + 256 * m]);
+    if (FOLD > 0) {
+        constexpr int DD = 1 << FOLD, NP = N >> FOLD, MP = 16 >> FOLD;     // decimation, inverse size, bins per lane
+        // bin t + 256 m folds onto t + 256 (m mod MP): inside the lane
+        float2 *A = S, *B = S + NP;
+#pragma unroll
+        for (int mp = 0; mp < MP; ++mp) {
+            float2 f = v[mp];
+#pragma unroll
+            for (int a = 1; a < DD; ++a) f = c_add(f, v[mp + a * MP]);
+            A[t + 256 * mp] = f;
+        }
+        __syncthreads();
+        // (4096/D)-point backward transform, radix-4 Stockham passes (+ one radix-2) between the halves of S
+        float2 *src = A, *dst = B;
+        int p = 1;
+        constexpr int T4 = NP >> 2;
+        while (p * 4 <= NP) {
+            const int tstep = (NP / (4 * p)) << FOLD;              // step in the 4096-entry twiddle table
+            for (int i = t; i < T4; i += 256) {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 2) + k;
+                const int m = k * tstep;
+                float2 u0 = src[i], u1 = src[i + T4], u2 = src[i + 2 * T4], u3 = src[i + 3 * T4];
+                if (p > 1) {
+                    u1 = cmul2(u1, tw<false>(twiddle, m));
+                    u2 = cmul2(u2, tw<false>(twiddle, 2 * m));
+                    u3 = cmul2(u3, tw<false>(twiddle, 3 * m));
+                }
+                radix4<false>(u0, u1, u2, u3);
+                dst[j] = u0; dst[j + p] = u1; dst[j + 2 * p] = u2; dst[j + 3 * p] = u3;
+            }
+            __syncthreads();
+            float2 *tmp = src; src = dst; dst = tmp;
+            p <<= 2;
+        }
+        if (p < NP) {                                             // one radix-2 pass, p == NP/2
+            constexpr int T2 = NP >> 1;
+            for (int i = t; i < T2; i += 256) {
+                float2 u0 = src[i], u1 = src[i + T2];
+                if (p > 1) u1 = cmul2(u1, tw<false>(twiddle, (i & (p - 1)) << FOLD));
+                dst[i] = c_add(u0, u1);
+                dst[i + p] = c_sub(u0, u1);
+            }
+            __syncthreads();
+            float2 *tmp = src; src = dst; dst = tmp;
+        }
+        const int nvalid = L >> FOLD;                             // outputs of this block
+        for (int r = t; r < nvalid; r += 256) {
+            const long long n = b * nvalid + r;
+            if (n < nout) {
+                if (REAL) ((float *)out_v)[n] = src[r].x;
+                else ((float2 *)out_v)[n] = src[r];
+            }
+        }
+        return;
+    }
     dft16<false>(v);                                     // inverse pass 1 on the same registers
     fft4096_mid_passes<false>(v, S, twiddle, t);         // v[m] = z[t + 256 m]
 #pragma unroll
@@ -636,11 +695,13 @@ fftfilt_hist_kernel(const float2 *__restrict__ in, long long nin, const float2 *
     hist_new[j] = i >= 0 ? in[i] : hist_old[i + hlen];
 }
 
-int ols_build(const float *taps_cplx, int ntaps, int decim, DevBuf &d_tw, DevBuf &d_H, int *L)
+int ols_build(const float *taps_cplx, int ntaps, int decim, DevBuf &d_tw, DevBuf &d_H, int *L, int *fold)
 {
     if (ntaps < 1 || ntaps > OLS_MAX_TAPS || decim < 1 || (OLS_N - (ntaps - 1)) / decim < 1)
         return fail(GRHIP_EINVAL, "overlap-save engine: %d taps / decimation %d not supported", ntaps, decim);
     *L = ((OLS_N - (ntaps - 1)) / decim) * decim;
+    // decimations 2, 4, 8, 16: folded spectrum + small inverse (see fftfilt4096_kernel)
+    *fold = decim == 2 ? 1 : decim == 4 ? 2 : decim == 8 ? 3 : decim == 16 ? 4 : 0;
     std::vector<float2> tw((size_t)OLS_N), H((size_t)OLS_N);
     std::vector<double> cs((size_t)OLS_N), sn((size_t)OLS_N);
     for (int k = 0; k < OLS_N; ++k) {
@@ -657,6 +718,12 @@ int ols_build(const float *taps_cplx, int ntaps, int decim, DevBuf &d_tw, DevBuf
             ar += tr * cs[m] - ti * sn[m];
             ai += tr * sn[m] + ti * cs[m];
         }
+        if (*fold) {        // advance the block by ntaps-1 samples: the first valid output becomes output 0
+            const int m = (int)(((long long)k * (ntaps - 1)) & (OLS_N - 1));
+            const double cr = cs[m], ci = -sn[m];               // e^{+j 2 pi k (ntaps-1) / N}
+            const double r2 = ar * cr - ai * ci, i2 = ar * ci + ai * cr;
+            ar = r2; ai = i2;
+        }
         H[k] = make_float2((float)(ar * sc), (float)(ai * sc));
     }
     int rc = d_tw.reserve(tw.size() * sizeof(float2));
@@ -667,26 +734,36 @@ int ols_build(const float *taps_cplx, int ntaps, int decim, DevBuf &d_tw, DevBuf
     return GRHIP_OK;
 }
 
-int launch_fftfilt4096(const float2 *in, long long nin, const float2 *hist, int ntaps, const float2 *twiddle,
-                       const float2 *H, float2 *out, long long nout, int decim, int L, hipStream_t st)
+template <bool REAL>
+static int launch_fftfilt4096_t(const void *in, long long nin, const void *hist, int ntaps, const float2 *twiddle,
+                                const float2 *H, void *out, long long nout, int decim, int L, int fold, hipStream_t st)
 {
     if (nout <= 0) return GRHIP_OK;
-    const long long nblk = (nin + L - 1) / L;
-    hipLaunchKernelGGL(fftfilt4096_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, (const void *)in, nin,
-                       (const void *)hist, ntaps, twiddle, H, (void *)out, nout, decim, L);
+    const unsigned nblk = (unsigned)((nin + L - 1) / L);
+#define GRHIP_OLS_LAUNCH(F) hipLaunchKernelGGL((fftfilt4096_kernel<REAL, F>), dim3(nblk), dim3(256), 0, st, in, nin, hist, ntaps, \
+                                               twiddle, H, out, nout, decim, L)
+    switch (fold) {
+    case 1: GRHIP_OLS_LAUNCH(1); break;
+    case 2: GRHIP_OLS_LAUNCH(2); break;
+    case 3: GRHIP_OLS_LAUNCH(3); break;
+    case 4: GRHIP_OLS_LAUNCH(4); break;
+    default: GRHIP_OLS_LAUNCH(0); break;
+    }
+#undef GRHIP_OLS_LAUNCH
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
 }
 
-int launch_fftfilt4096_real(const float *in, long long nin, const float *hist, int ntaps, const float2 *twiddle,
-                            const float2 *H, float *out, long long nout, int decim, int L, hipStream_t st)
+int launch_fftfilt4096(const float2 *in, long long nin, const float2 *hist, int ntaps, const float2 *twiddle,
+                       const float2 *H, float2 *out, long long nout, int decim, int L, int fold, hipStream_t st)
 {
-    if (nout <= 0) return GRHIP_OK;
-    const long long nblk = (nin + L - 1) / L;
-    hipLaunchKernelGGL(fftfilt4096_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, (const void *)in, nin,
-                       (const void *)hist, ntaps, twiddle, H, (void *)out, nout, decim, L);
-    GRHIP_HIP(hipGetLastError());
-    return GRHIP_OK;
+    return launch_fftfilt4096_t<false>(in, nin, hist, ntaps, twiddle, H, out, nout, decim, L, fold, st);
+}
+
+int launch_fftfilt4096_real(const float *in, long long nin, const float *hist, int ntaps, const float2 *twiddle,
+                            const float2 *H, float *out, long long nout, int decim, int L, int fold, hipStream_t st)
+{
+    return launch_fftfilt4096_t<true>(in, nin, hist, ntaps, twiddle, H, out, nout, decim, L, fold, st);
 }
 
 int launch_fftfilt_hist(const float2 *in, long long nin, const float2 *hist_old, float2 *hist_new, int hlen, hipStream_t st)

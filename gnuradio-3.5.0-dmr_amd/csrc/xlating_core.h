@@ -35,7 +35,7 @@ struct XlatingCore {
     // FAST mode for the shapes the tiled kernel does not take (other decimations, long prototypes):
     // overlap-save engine (fft_kernels.hip) + rotator table multiply
     bool use_ols = false, prefer_ols = false;
-    int ols_L = 0;
+    int ols_L = 0, ols_fold = 0;
     DevBuf d_ols_tw, d_ols_H;
     DevBuf scratch_y;
     SchedBuf sched;                             // tile queue of the tiled kernel (one launch at a time per handle)

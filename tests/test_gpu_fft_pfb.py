@@ -144,7 +144,7 @@ def test_pfb_tone_lands_in_its_channel_full_size(gpu, wl):
         assert np.argmax(p) == k and p[k] > 100 * np.delete(p, k).max()
 
 
-@pytest.mark.parametrize("ntaps,decim", [(1, 1), (7, 1), (64, 2), (256, 4), (255, 5), (1000, 1), (2049, 3),
+@pytest.mark.parametrize("ntaps,decim", [(1, 1), (7, 1), (64, 2), (256, 4), (255, 5), (1000, 1), (2049, 3), (300, 16), (100, 8),
                                          (2500, 1)])      # > 2049 taps: the batched overlap-add path
 def test_fft_filter_ccc_vs_oracle_and_direct_form(gpu, po, ntaps, decim):
     """gr_fft_filter_ccc (overlap-add): equal to the oracle's restatement of

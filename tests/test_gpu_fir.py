@@ -45,7 +45,8 @@ def test_fir_generic_mode_bit_exact(gpu, po, kind, ntaps, decim):
 
 @pytest.mark.parametrize("kind", ["ccf", "ccc"])
 @pytest.mark.parametrize("ntaps,decim", [(1, 1), (3, 1), (64, 1), (65, 2), (256, 4), (255, 4), (256, 1), (31, 8), (40, 3),
-                                         (200, 3), (1500, 1), (2049, 5), (600, 8)])    # last four: overlap-save engine
+                                         (200, 3), (1500, 1), (2049, 5), (600, 8), (700, 16), (1100, 2),
+                                         (900, 4)])    # from (200, 3) on: overlap-save engine (folded inverse at D = 2..16)
 def test_fir_fast_mode_tolerance(gpu, po, kind, ntaps, decim):
     rng = np.random.default_rng(1000 + ntaps * 10 + decim)
     n = 5003           # not a multiple of the tile: exercises the ragged tail
@@ -149,7 +150,7 @@ def test_xlating_generic_bit_exact_and_rotator_carry(gpu, po, wl):
     assert bits_equal(got, ref)
 
 
-@pytest.mark.parametrize("decim,ntaps", [(10, 256), (5, 1200), (25, 400)])
+@pytest.mark.parametrize("decim,ntaps", [(10, 256), (5, 1200), (25, 400), (8, 300), (16, 512)])
 def test_xlating_fast_other_decimations(gpu, po, wl, decim, ntaps):
     """decimations the tiled kernel does not take (and prototypes beyond its 1024 taps): FAST mode goes
     through the overlap-save engine + rotator table (+ stand-alone demodulator), chunked calls included"""
@@ -397,7 +398,7 @@ def test_errors_and_edges(gpu):
 
 @pytest.mark.parametrize("ntaps,decim,n", [(1, 1, 9), (3, 1, 4097), (256, 1, 100_001), (255, 2, 50_000), (64, 2, 33_333),
                                            (17, 1, 2), (300, 4, 5000), (1500, 1, 20_001), (100, 3, 777),
-                                           (2049, 7, 3000)])      # last four: real-data overlap-save engine
+                                           (2049, 7, 3000), (500, 8, 2000), (500, 16, 999)])      # from (300, 4) on: real-data overlap-save engine
 def test_fir_fff_fast_mode(gpu, po, ntaps, decim, n):
     """gr_fir_filter_fff through the tiled kernel's float-pair mode (decimation 1, 2), the real-data
     overlap-save engine (other decimations, more than 1024 taps) or the generic-order kernel (short

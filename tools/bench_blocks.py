@@ -139,3 +139,9 @@ blk = g.freq_xlating_fir_filter_ccc(20, wl.lowpass_taps(400, 0.02, 1.0).astype(n
 def run_xl20():
     blk.reset(); blk.work_device(n // 20, x, y, st)
 report("freq_xlating_fir_filter_ccc 400t D=20 (overlap-save engine)", timeit(run_xl20, reps=10), n, 8.4)
+
+y16 = torch.empty((n // 16, 2), device=dev)
+blk16 = g.freq_xlating_fir_filter_ccc(16, wl.lowpass_taps(400, 0.02, 1.0).astype(np.complex64), c["center_freq"], c["fs"])
+def run_xl16():
+    blk16.reset(); blk16.work_device(n // 16, x, y16, st)
+report("freq_xlating_fir_filter_ccc 400t D=16 (overlap-save engine, folded 256-point inverse)", timeit(run_xl16, reps=10), n, 8.5)
