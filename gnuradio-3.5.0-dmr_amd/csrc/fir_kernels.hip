@@ -133,17 +133,37 @@ int launch_fir_generic(FirKind kind, const float *taps_rev, int ntaps, const voi
 // ===========================================================================
 __global__ void __launch_bounds__(256)
 quad_demod_kernel(const float2 *__restrict__ in, float *__restrict__ out, long long n_out, float gain,
-                  const float *__restrict__ tab)
+                  const float *__restrict__ tab, int vec)
 {
-    long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i0 >= n_out) return;
-    // in[0] is the history item: output i uses in[i+1] and in[i]
-    float2 v[5];
+    // arctangent table as (tab[k], tab[k+1]) pairs in LDS: one 8-byte read per interpolation
+    __shared__ float2 s_tab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_tab[i] = make_float2(tab[i], tab[i + 1]);
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    for (long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < n_out; i0 += stride) {
+        // in[0] is the history item: output i uses in[i+1] and in[i]
+        float2 v[5];
+        if (vec && i0 + 4 <= n_out) {
+            // 16-byte loads and one 16-byte store per lane (rows are 16-byte aligned)
+            const float4 a = *reinterpret_cast<const float4 *>(in + i0);
+            const float4 b = *reinterpret_cast<const float4 *>(in + i0 + 2);
+            v[0] = make_float2(a.x, a.y); v[1] = make_float2(a.z, a.w);
+            v[2] = make_float2(b.x, b.y); v[3] = make_float2(b.z, b.w);
+            v[4] = in[i0 + 4];
+            float4 o;
+            o.x = quad_demod_one(v[1], v[0], gain, s_tab);
+            o.y = quad_demod_one(v[2], v[1], gain, s_tab);
+            o.z = quad_demod_one(v[3], v[2], gain, s_tab);
+            o.w = quad_demod_one(v[4], v[3], gain, s_tab);
+            *reinterpret_cast<float4 *>(out + i0) = o;
+        } else {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = (i0 + k <= n_out) ? in[i0 + k] : make_float2(0.f, 0.f);
+            for (int k = 0; k < 5; ++k) v[k] = (i0 + k <= n_out) ? in[i0 + k] : make_float2(0.f, 0.f);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (i0 + k < n_out) out[i0 + k] = quad_demod_one(v[k + 1], v[k], gain, tab);
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k < n_out) out[i0 + k] = quad_demod_one(v[k + 1], v[k], gain, s_tab);
+        }
+    }
 }
 
 // y[n] = y[n] * phase[n] with the reference's unfused complex product (gr_rotator.h:43)
@@ -170,8 +190,11 @@ int launch_quad_demod(const float2 *in, float *out, long long n_out, float gain,
 {
     if (n_out <= 0) return GRHIP_OK;
     long long lanes = (n_out + 3) / 4;
-    dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
-    hipLaunchKernelGGL(quad_demod_kernel, grid, block, 0, st, in, out, n_out, gain, atan_tab);
+    long long blocks = (lanes + 255) / 256;
+    if (blocks > 8192) blocks = 8192;          // grid-stride: 32 workgroups per CU are plenty, the table is loaded once each
+    dim3 grid((unsigned)blocks), block(256);
+    const int vec = ((((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(quad_demod_kernel, grid, block, 0, st, in, out, n_out, gain, atan_tab, vec);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
 }
