@@ -44,7 +44,8 @@ namespace grhip {
 // per CU.  R = 4: twice the LDS reads per FMA but 3 workgroups (12 waves) per CU.
 #ifndef GRHIP_EXP
 #define GRHIP_EXP 0        // timing experiments only (wrong results): 1 no tap loads, 2 no window loads in the MAC loop,
-                           // 4 prefetch in one burst before the MAC loop, 8 no MAC loop, 16 no demodulator arithmetic
+                           // 4 prefetch in one burst before the MAC loop, 8 no MAC loop, 16 no demodulator arithmetic,
+                           // 32 wave priority by phase (no effect), 64 first blocks of a pass requested a pass ahead
 #endif
 #ifndef GRHIP_TILED_R
 #define GRHIP_TILED_R 8
@@ -453,6 +454,16 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
 #if GRHIP_EXP & 8
         fetch(rsrc_n, voff_n, -1);
 #else
+#if GRHIP_EXP & 64
+        // first two sample blocks of a pass, requested one pass ahead (the first step of a pass would
+        // otherwise wait for them)
+        f32x2 nA[R], nB[R];
+        {
+            const f32x2 *x0 = reinterpret_cast<const f32x2 *>(xs) + lane_base;
+#pragma unroll
+            for (int j = 0; j < R; ++j) { nA[j] = x0[j]; nB[j] = x0[(R + 1) + j]; }
+        }
+#endif
 #pragma unroll
         for (int p = 0; p < D; ++p) {
             const f32x2 *xp = reinterpret_cast<const f32x2 *>(xs) + p * PS + lane_base;
@@ -468,8 +479,18 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
                 if (CTAPS) step_cplx(cur, nxt, p * nb + k);
                 else step_real(cur, nxt, p * nb + k);
             };
+#if GRHIP_EXP & 64
+#pragma unroll
+            for (int j = 0; j < R; ++j) { wA[j] = nA[j]; wB[j] = nB[j]; }
+            if (p + 1 < D) {
+                const f32x2 *x1 = xp + PS;
+#pragma unroll
+                for (int j = 0; j < R; ++j) { nA[j] = x1[j]; nB[j] = x1[(R + 1) + j]; }
+            }
+#else
             load_blk(wA, 0);
             load_blk(wB, 1);
+#endif
 #if !(GRHIP_EXP & 4)
             // this pass's share of the next tile's HBM loads, issued while the first two sample
             // blocks are on their way from LDS (p is a compile-time constant: the pass loop is unrolled)
