@@ -9,7 +9,7 @@ __all__ = [
     "MODE_FAST", "MODE_GENERIC",
     "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
-    "clock_recovery_mm_ff", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb",
+    "clock_recovery_mm_ff", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "stream_to_streams", "streams_to_stream",
     "fft_vcc", "fft_filter_ccc", "pfb_channelizer_ccf", "dmr_chain", "run_sync_block",
 ]
 
@@ -509,6 +509,54 @@ class unpack_k_bits_bb(_Block):
         L.grhip_unpack_k_bits_bb_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         n = _check(L.grhip_unpack_k_bits_bb_work(self._h, int(noutput_items), _ptr(x), _ptr(out)))
         return out[:n]
+
+
+class _stream_adapter(_Block):
+    _destroy = "grhip_stream_adapter_destroy"
+    _split = 1
+
+    def __init__(self, item_size, nstreams, device=0):
+        _Block.__init__(self)
+        L = lib()
+        L.grhip_stream_adapter_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, C.c_int]
+        _check(L.grhip_stream_adapter_create(C.byref(self._h), self._split, int(item_size), int(nstreams), int(device)))
+        self.item_size, self.nstreams = int(item_size), int(nstreams)
+
+    def _work(self, n, single, streams):
+        L = lib()
+        arr = (C.c_void_p * self.nstreams)(*[s.ctypes.data for s in streams])
+        L.grhip_stream_adapter_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        return _check(L.grhip_stream_adapter_work(self._h, int(n), single.ctypes.data, arr))
+
+    def work_device(self, n_items_per_stream, d_single, d_streams, stream_stride_items, stream=None):
+        L = lib()
+        L.grhip_stream_adapter_work_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        return _check(L.grhip_stream_adapter_work_device(self._h, int(n_items_per_stream), _devptr(d_single),
+                                                         _devptr(d_streams), int(stream_stride_items), _stream(stream)))
+
+
+class stream_to_streams(_stream_adapter):
+    """gr.stream_to_streams(item_size, nstreams): work(noutput_items, input) -> list of nstreams arrays"""
+    _split = 1
+
+    def work(self, noutput_items, input_items):
+        x = np.ascontiguousarray(input_items)
+        assert x.dtype.itemsize == self.item_size
+        outs = [np.zeros(noutput_items, dtype=x.dtype) for _ in range(self.nstreams)]
+        self._work(noutput_items, x, outs)
+        return outs
+
+
+class streams_to_stream(_stream_adapter):
+    """gr.streams_to_stream(item_size, nstreams): work(noutput_items, [inputs]) -> one array"""
+    _split = 0
+
+    def work(self, noutput_items, input_items):
+        ins = [np.ascontiguousarray(a) for a in input_items]
+        assert noutput_items % self.nstreams == 0 and ins[0].dtype.itemsize == self.item_size
+        out = np.zeros(noutput_items, dtype=ins[0].dtype)
+        self._work(noutput_items // self.nstreams, out, ins)
+        return out
 
 
 class correlate_access_code_bb(_Block):

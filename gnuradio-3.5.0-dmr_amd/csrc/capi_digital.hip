@@ -76,6 +76,11 @@ struct grhip_unpack_k_bits_bb : HandleBase {
     unsigned k = 1;
 };
 
+struct grhip_stream_adapter : HandleBase {
+    bool split = true;
+    size_t item_size = 1, nstreams = 1;
+};
+
 struct grhip_correlate_access_code_bb : HandleBase {
     CorrParams p;
     unsigned long long flag_bit = 0;
@@ -359,6 +364,70 @@ int grhip_unpack_k_bits_bb_work(grhip_unpack_k_bits_bb *h, int noutput_items, co
     GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, n, hipMemcpyDeviceToHost, st));
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
+}
+
+// ---- stream_to_streams / streams_to_stream ------------------------------------------
+int grhip_stream_adapter_create(grhip_stream_adapter **h, int split, size_t item_size, size_t nstreams, int device)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    if (item_size == 0 || nstreams == 0 || nstreams > 65536) return fail(GRHIP_EINVAL, "bad item_size / nstreams");
+    auto *b = new (std::nothrow) grhip_stream_adapter();
+    if (!b) return fail(GRHIP_ENOMEM, "alloc");
+    b->split = split != 0; b->item_size = item_size; b->nstreams = nstreams;
+    int rc = b->init_device(device);
+    if (rc) { b->destroy_base(); delete b; return rc; }
+    *h = b;
+    return GRHIP_OK;
+}
+
+void grhip_stream_adapter_destroy(grhip_stream_adapter *h)
+{
+    if (!h) return;
+    h->destroy_base();
+    delete h;
+}
+
+int grhip_stream_adapter_work_device(grhip_stream_adapter *h, int n, void *d_single, void *d_streams,
+                                     size_t stream_stride_items, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (n < 0) return fail(GRHIP_EINVAL, "negative item count");
+    if (stream_stride_items < (size_t)n) return fail(GRHIP_EINVAL, "stream stride shorter than the streams");
+    int rc = h->bind();
+    if (rc) return rc;
+    rc = launch_streams(h->split, d_single, d_streams, (long long)stream_stride_items, (int)h->nstreams, h->item_size, n,
+                        h->pick(stream));
+    return rc ? rc : n;
+}
+
+int grhip_stream_adapter_work(grhip_stream_adapter *h, int n, void *single, void *const *streams)
+{
+    if (!h || !streams) return fail(GRHIP_EINVAL, "null argument");
+    if (n < 0) return fail(GRHIP_EINVAL, "negative item count");
+    if (n == 0) return 0;
+    int rc = h->bind();
+    if (rc) return rc;
+    const size_t per = (size_t)n * h->item_size, tot = per * h->nstreams;
+    if ((rc = h->stage_in.reserve(tot))) return rc;
+    if ((rc = h->stage_out.reserve(tot))) return rc;
+    hipStream_t st = h->own_stream;
+    // stage_in holds the single stream, stage_out the nstreams streams back to back
+    if (h->split) {
+        GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, single, tot, hipMemcpyHostToDevice, st));
+    } else {
+        for (size_t j = 0; j < h->nstreams; ++j)
+            GRHIP_HIP(hipMemcpyAsync((char *)h->stage_out.p + j * per, streams[j], per, hipMemcpyHostToDevice, st));
+    }
+    if ((rc = launch_streams(h->split, h->stage_in.p, h->stage_out.p, n, (int)h->nstreams, h->item_size, n, st))) return rc;
+    if (h->split) {
+        for (size_t j = 0; j < h->nstreams; ++j)
+            GRHIP_HIP(hipMemcpyAsync(streams[j], (char *)h->stage_out.p + j * per, per, hipMemcpyDeviceToHost, st));
+    } else {
+        GRHIP_HIP(hipMemcpyAsync(single, h->stage_in.p, tot, hipMemcpyDeviceToHost, st));
+    }
+    GRHIP_HIP(hipStreamSynchronize(st));
+    return n;
 }
 
 // ---- correlate_access_code_bb ----------------------------------------------------

@@ -25,6 +25,10 @@ int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipSt
 // pager_slicer_fb: d_avg[s] carried in device memory; streams s at in + s*in_stride / out + s*out_stride
 int launch_pager_slicer(float *d_avg, int n_streams, float alpha, float beta, const float *in, long long in_stride,
                         unsigned char *out, long long out_stride, long long n, hipStream_t st);
+// gr_stream_to_streams (split = true) / gr_streams_to_stream (split = false): stream j of `multi` starts at
+// multi + j * multi_stride_items items
+int launch_streams(bool split, void *single, void *multi, long long multi_stride_items, int nstreams, size_t item_size,
+                   long long n_items_per_stream, hipStream_t st);
 int launch_unpack_k_bits(unsigned k, const unsigned char *in, unsigned char *out, long long noutput_items, hipStream_t st);
 
 // device-resident state of one digital_correlate_access_code_bb instance

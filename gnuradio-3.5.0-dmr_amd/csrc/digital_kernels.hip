@@ -446,4 +446,53 @@ int launch_correlate(const CorrParams &p, CorrState *state, int n_streams, const
     return GRHIP_OK;
 }
 
+// ===========================================================================
+// gr_stream_to_streams / gr_streams_to_stream (general/gr_stream_to_streams.cc:46-66,
+// general/gr_streams_to_stream.cc:46-69): item i of stream j <-> item i*nstreams + j of the
+// single stream.  One lane per i: it touches nstreams consecutive items of the single stream
+// (coalesced across the wave) and one item of each separate stream (coalesced per stream).
+// Items are copied as 8-byte words when their size allows it, else 4-byte or single bytes.
+// ===========================================================================
+template <class W, bool SPLIT>
+__global__ void __launch_bounds__(256)
+streams_kernel(W *__restrict__ single, W *__restrict__ multi, long long multi_stride_w, int nstreams, int wpi, long long n)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        for (int j = 0; j < nstreams; ++j) {
+            W *a = single + (i * nstreams + j) * wpi;
+            W *b = multi + (long long)j * multi_stride_w + i * wpi;
+            for (int w = 0; w < wpi; ++w) {
+                if (SPLIT) b[w] = a[w];
+                else a[w] = b[w];
+            }
+        }
+    }
+}
+
+int launch_streams(bool split, void *single, void *multi, long long multi_stride_items, int nstreams, size_t item_size,
+                   long long n_items_per_stream, hipStream_t st)
+{
+    if (n_items_per_stream <= 0 || nstreams <= 0) return GRHIP_OK;
+    long long blocks = (n_items_per_stream + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const uintptr_t al = (uintptr_t)single | (uintptr_t)multi | (uintptr_t)(multi_stride_items * (long long)item_size);
+#define GRHIP_STREAMS(W)                                                                                         \
+    do {                                                                                                       \
+        const int wpi = (int)(item_size / sizeof(W));                                                          \
+        const long long msw = multi_stride_items * wpi;                                                        \
+        if (split) hipLaunchKernelGGL((streams_kernel<W, true>), dim3((unsigned)blocks), dim3(256), 0, st, (W *)single, \
+                                      (W *)multi, msw, nstreams, wpi, n_items_per_stream);                    \
+        else hipLaunchKernelGGL((streams_kernel<W, false>), dim3((unsigned)blocks), dim3(256), 0, st, (W *)single,      \
+                                (W *)multi, msw, nstreams, wpi, n_items_per_stream);                          \
+    } while (0)
+    if (item_size % 8 == 0 && (al & 7) == 0) GRHIP_STREAMS(unsigned long long);
+    else if (item_size % 4 == 0 && (al & 3) == 0) GRHIP_STREAMS(unsigned int);
+    else GRHIP_STREAMS(unsigned char);
+#undef GRHIP_STREAMS
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
 }  // namespace grhip

@@ -260,6 +260,28 @@ GRHIP_API int grhip_unpack_k_bits_bb_work_device(grhip_unpack_k_bits_bb *h, int 
                                                  const unsigned char *d_in, unsigned char *d_out, void *stream);
 
 /* ======================================================================
+ * gr_stream_to_streams / gr_streams_to_stream  (the adapters either side of the
+ * channeliser)
+ *   replace gr_make_stream_to_streams(size_t item_size, size_t nstreams) and
+ *           gr_make_streams_to_stream(size_t item_size, size_t nstreams)
+ *   general/gr_stream_to_streams.cc:32-66 (gr_sync_decimator by nstreams),
+ *   general/gr_streams_to_stream.cc:32-69 (gr_sync_interpolator by nstreams)
+ * `split` selects the direction at creation.  work(): `streams` is the array of nstreams
+ * host pointers the scheduler hands over; work_device(): stream j lives at
+ * d_streams + j * stream_stride_items items (the convention of the PFB's inputs).
+ * n_items_per_stream = noutput_items for stream_to_streams, noutput_items / nstreams for
+ * streams_to_stream (which must divide, .cc:56).
+ * ====================================================================== */
+typedef struct grhip_stream_adapter grhip_stream_adapter;
+GRHIP_API int grhip_stream_adapter_create(grhip_stream_adapter **h, int split, size_t item_size, size_t nstreams,
+                                          int device);
+GRHIP_API void grhip_stream_adapter_destroy(grhip_stream_adapter *h);
+GRHIP_API int grhip_stream_adapter_work(grhip_stream_adapter *h, int n_items_per_stream, void *single,
+                                        void *const *streams);
+GRHIP_API int grhip_stream_adapter_work_device(grhip_stream_adapter *h, int n_items_per_stream, void *d_single,
+                                               void *d_streams, size_t stream_stride_items, void *stream);
+
+/* ======================================================================
  * digital_correlate_access_code_bb
  *   replaces digital_make_correlate_access_code_bb(const std::string&
  *       access_code, int threshold)

@@ -199,3 +199,20 @@ def test_four_level_chain_tail(gpu, po, wl):
     o_out = po.CorrelateAccessCode(code, 0).work(o_bits)
     assert np.array_equal(sym, o_sym) and np.array_equal(bits, o_bits) and np.array_equal(out, o_out)
     assert int((out & 2).sum()) // 2 >= 9               # the planted sync words are found
+
+
+@pytest.mark.parametrize("dtype,nstreams", [(np.complex64, 8), (np.float32, 3), (np.uint8, 5), (np.complex128, 2)])
+def test_stream_to_streams_and_back(gpu, dtype, nstreams):
+    """gr_stream_to_streams / gr_streams_to_stream (general/gr_stream_to_streams.cc:46-66): a pure
+    re-ordering, checked against numpy reshapes; 8-, 4-, 1- and 16-byte items"""
+    rng = np.random.default_rng(nstreams)
+    n = 10_007
+    raw = rng.integers(0, 255, n * nstreams * np.dtype(dtype).itemsize, dtype=np.uint8)
+    x = raw.view(dtype).copy()
+    s2s = gpu.stream_to_streams(np.dtype(dtype).itemsize, nstreams)
+    outs = s2s.work(n, x)
+    want = x.view(np.uint8).reshape(n, nstreams, -1)
+    for j in range(nstreams):
+        assert np.array_equal(outs[j].view(np.uint8).reshape(n, -1), want[:, j, :])
+    back = gpu.streams_to_stream(np.dtype(dtype).itemsize, nstreams).work(n * nstreams, outs)
+    assert np.array_equal(back.view(np.uint8), x.view(np.uint8))
