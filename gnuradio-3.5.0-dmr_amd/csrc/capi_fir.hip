@@ -40,6 +40,22 @@ static int upload(DevBuf &b, const void *src, size_t bytes)
 // ============================================================================
 // XlatingCore
 // ============================================================================
+// the high-decimation direct kernel where it beats (or replaces) the overlap-save engine
+static bool hidec_wanted(int decim, int ntaps, bool ctaps, bool have_ols)
+{
+    static int knob = -1;                                  // GRHIP_HIDEC=0 / 1: tuning knob (never / whenever supported)
+    if (knob < 0) { const char *e = getenv("GRHIP_HIDEC"); knob = e ? 2 + atoi(e) : 0; }
+    if (!hidec_supported(decim, ntaps)) return false;
+    if (knob == 2) return false;
+    if (knob == 3) return true;
+    if (!have_ols) return true;
+    // work per input sample in units the measurements line up on (tools/bench_decim.py): taps per polyphase
+    // component, twice for complex taps, over the share of lanes a tile keeps busy
+    const int tn = hidec_outputs_per_tile(decim, ntaps);
+    const double cost = (double)ntaps / decim * (ctaps ? 2.0 : 1.0) * 512.0 / (tn < 512 ? tn : 512);
+    return cost <= 110.0;
+}
+
 int XlatingCore::build(int device)
 {
     // build_composite_fir (filter/gr_freq_xlating_fir_filter_XXX.cc.t:72-83)
@@ -122,6 +138,13 @@ int XlatingCore::build(int device)
     }
     // same crossover as gr_fir_filter (see there); single-stream calls only, batched launches stay tiled
     prefer_ols = use_ols && (!use_tiled || ntaps / decim > 120);
+    use_hidec = !use_tiled && hidec_wanted(decim, ntaps, true, use_ols);
+    if (use_hidec) {
+        std::vector<float> hp2;
+        hidec_pad_taps((const float *)ctaps.data(), ntaps, 2, decim, hp2);
+        rc = upload(d_hidec_taps, hp2.data(), hp2.size() * sizeof(float));
+        if (rc) return rc;
+    }
     reset();
     (void)device;
     return GRHIP_OK;
@@ -198,7 +221,7 @@ int XlatingCore::phase_before_pos(std::complex<float> *g)
 void XlatingCore::release()
 {
     d_taps_generic.release(); d_hp.release(); d_wtab.release(); d_stab.release(); d_vtab.release(); d_rot.release();
-    scratch_y.release(); sched.release(); d_ols_tw.release(); d_ols_H.release();
+    scratch_y.release(); sched.release(); d_ols_tw.release(); d_ols_H.release(); d_hidec_taps.release();
 }
 
 // run the FIR + rotator (+ demod) for n_out outputs on device pointers.
@@ -218,7 +241,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         rc = ensure_rot(n_out, &gtab);
         if (rc) return rc;
     }
-    const bool ols_now = mode == GRHIP_MODE_FAST && prefer_ols && !batched;
+    const bool ols_now = mode == GRHIP_MODE_FAST && (prefer_ols || (use_hidec && !use_tiled)) && !batched;
     if (mode == GRHIP_MODE_FAST && use_tiled && !ols_now) {
         FirTiledArgs a;
         memset(&a, 0, sizeof(a));
@@ -266,9 +289,14 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
             y = scratch_y.as<float2>() + 1;
             GRHIP_HIP(hipMemcpyAsync(scratch_y.p, y_prev, sizeof(float2), hipMemcpyDeviceToDevice, st));
         }
-        rc = launch_fftfilt4096(d_in + (ntaps - 1), (n_out - 1) * decim + 1, d_in, ntaps, d_ols_tw.as<float2>(),
-                                d_ols_H.as<float2>(), y, n_out, decim, ols_L, ols_fold, st);
-        if (!rc) rc = launch_rotate(y, gtab, n_out, st);
+        if (use_hidec) {
+            rc = launch_fir_hidec(true, d_hidec_taps.as<float>(), ntaps, decim, d_in, (n_out - 1) * decim + ntaps, y, n_out,
+                                  gtab, st);                 // rotator multiply inside
+        } else {
+            rc = launch_fftfilt4096(d_in + (ntaps - 1), (n_out - 1) * decim + 1, d_in, ntaps, d_ols_tw.as<float2>(),
+                                    d_ols_H.as<float2>(), y, n_out, decim, ols_L, ols_fold, st);
+            if (!rc) rc = launch_rotate(y, gtab, n_out, st);
+        }
         if (rc) return rc;
         if (demod) {
             rc = launch_quad_demod(scratch_y.as<float2>(), d_demod, n_out, gain, atan_tab, st);
@@ -320,6 +348,9 @@ struct grhip_fir_filter : HandleBase {
     bool use_ols = false, prefer_ols = false;
     int ols_L = 0, ols_fold = 0;
     DevBuf d_ols_tw, d_ols_H;
+    // ... and the high-decimation direct kernel where a polyphase component has few taps (fir_kernels.hip)
+    bool use_hidec = false;
+    DevBuf d_hidec_taps;
 
     int tw() const { return kind == FIR_CCC ? 2 : 1; }
     size_t in_item() const { return kind == FIR_FFF ? 4 : 8; }
@@ -360,6 +391,13 @@ struct grhip_fir_filter : HandleBase {
         // Measured on MI355X (profiles/r01_blocks_bench.log): the tiled kernel runs at about
         // 15000 / (taps per phase) Gsamples/s, the overlap-save engine at about 125 whatever the filter:
         // fast convolution takes over above ~120 taps per phase.
+        use_hidec = !use_tiled && kind != FIR_FFF && hidec_wanted(decim, ntaps, kind == FIR_CCC, use_ols);
+        if (use_hidec) {
+            std::vector<float> hp2;
+            hidec_pad_taps(rev.data(), ntaps, tw(), decim, hp2);
+            rc = upload(d_hidec_taps, hp2.data(), hp2.size() * sizeof(float));
+            if (rc) return rc;
+        }
         // (float data: the engine only where the float-pair mode of the tiled kernel does not reach)
         prefer_ols = use_ols && (!use_tiled || (kind != FIR_FFF && ntaps / decim > 120));
         return GRHIP_OK;
@@ -385,6 +423,9 @@ struct grhip_fir_filter : HandleBase {
             return launch_fir_generic(kind, d_taps_rev.as<float>(), ntaps, (const float *)d_in + (n - 1) * dec,
                                       (float *)d_out + (n - 1), 1, dec, nullptr, st);
         }
+        if (mode == GRHIP_MODE_FAST && use_hidec && dec == decim)
+            return launch_fir_hidec(kind == FIR_CCC, d_hidec_taps.as<float>(), ntaps, dec, (const float2 *)d_in,
+                                    (n - 1) * dec + ntaps, (float2 *)d_out, n, nullptr, st);
         if (mode == GRHIP_MODE_FAST && use_ols && (prefer_ols || !use_tiled) && dec == decim) {
             // y[n] = sum_k taps[k] x[nD + ntaps-1-k]: the ntaps-1 history items in front of d_in are the
             // engine's "previous call" samples, the rest is the stream
@@ -421,7 +462,7 @@ int grhip_fir_filter_create(grhip_fir_filter **h, const char *kind, int decimati
     f->kind = k; f->decim = decimation; f->mode = default_mode();
     int rc = f->init_device(device);
     if (!rc) rc = f->install(std::vector<float>(taps, taps + ntaps * f->tw()));
-    if (rc) { f->d_taps_rev.release(); f->d_hp.release(); f->sched.release(); f->d_ols_tw.release(); f->d_ols_H.release(); f->destroy_base(); delete f; return rc; }
+    if (rc) { f->d_taps_rev.release(); f->d_hp.release(); f->sched.release(); f->d_ols_tw.release(); f->d_ols_H.release(); f->d_hidec_taps.release(); f->destroy_base(); delete f; return rc; }
     *h = f;
     return GRHIP_OK;
 }
@@ -430,7 +471,7 @@ void grhip_fir_filter_destroy(grhip_fir_filter *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    h->d_taps_rev.release(); h->d_hp.release(); h->sched.release(); h->d_ols_tw.release(); h->d_ols_H.release();
+    h->d_taps_rev.release(); h->d_hp.release(); h->sched.release(); h->d_ols_tw.release(); h->d_ols_H.release(); h->d_hidec_taps.release();
     h->destroy_base();
     delete h;
 }

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 namespace grhip {
 
 enum FirKind { FIR_FFF = 0, FIR_CCF = 1, FIR_CCC = 2 };
@@ -59,6 +61,14 @@ int tiled_stab_len();
 int tiled_load_span();              // samples covered by one round of 16-byte loads of a workgroup
 int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiledArgs &a,
                      int n_streams, hipStream_t st);
+
+// high-decimation direct form (FAST mode): c[k] multiplies x[n*decim + k] (complex interleaved if ctaps), given
+// as hidec_pad_taps() lays them out; x item 0 = input[0] of output 0, items >= n_in read as zero; optional rotator table
+bool hidec_supported(int decim, int ntaps);
+int hidec_outputs_per_tile(int decim, int ntaps);
+void hidec_pad_taps(const float *taps_corr, int ntaps, int tw, int decim, std::vector<float> &out);
+int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in,
+                     float2 *y, long long n_out, const float2 *gtab, hipStream_t st);
 
 // in-place rotator multiply with a phase table (gr_rotator.h:43)
 int launch_rotate(float2 *y, const float2 *gtab, long long n, hipStream_t st);

@@ -18,6 +18,8 @@
 //      Epilogues: rotator multiply (xlating) and fused quadrature demod.
 #include "fir_kernels.h"
 
+#include <vector>
+
 #include <cstdlib>
 
 #include "device_math.h"
@@ -197,6 +199,153 @@ int launch_quad_demod(const float2 *in, float *out, long long n_out, float gain,
     hipLaunchKernelGGL(quad_demod_kernel, grid, block, 0, st, in, out, n_out, gain, atan_tab, vec);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
+}
+
+// ===========================================================================
+// High-decimation direct form (FAST mode, decimations the tiled kernel does not take, few taps per
+// polyphase component): y[n] = sum_k c[k] x[nD + k] costs ntaps/D MACs per INPUT sample, so at D = 20 and
+// 400 taps the job is to stream the input through, not to feed the FMA pipes.
+//  * a 256-lane workgroup stages the samples of Tn outputs ((Tn-1)D + ntaps of them, Tn even, as many as
+//    50 KB of LDS hold) and every lane computes TWO adjacent outputs, so that one LDS read feeds two MACs
+//    (taps c[k] and c[k-D]);
+//  * LDS layout: sample u lives in sub-array u mod 2P (P = largest power of two dividing D, so every lane
+//    of a wave reads the same sub-array for a given k) at index u / 2P: the lane stride is D/P, odd, hence
+//    conflict-free 8-byte reads whatever the decimation;
+//  * taps are wave-uniform scalar loads; 3 workgroups per CU cover each other's staging.
+// Optional rotator-table multiply (freq_xlating) with the reference's unfused product.
+// ===========================================================================
+constexpr int HIDEC_LDS_SAMPLES = 6400;           // 50 KB: three workgroups per CU
+
+__host__ __device__ inline int hidec_sub_log(int D)
+{
+    int v = 0;
+    while (((D >> v) & 1) == 0 && v < 4) ++v;     // P = 2^v divides D
+    return v + 1;                                  // sub-arrays: 2P
+}
+
+int hidec_outputs_per_tile(int D, int ntaps)
+{
+    int tn = (HIDEC_LDS_SAMPLES - ntaps) / D;
+    if (tn > 512) tn = 512;
+    return tn & ~1;
+}
+
+bool hidec_supported(int D, int ntaps)
+{
+    return D >= 3 && D <= 256 && ntaps >= 1 && ntaps <= 2048 && hidec_outputs_per_tile(D, ntaps) >= 128;
+}
+
+template <bool CTAPS, int V1>
+__global__ void __launch_bounds__(256, 3)
+fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__restrict__ taps_g, int ntaps, int D,
+                 int Tn, long long n_out, float2 *__restrict__ y, const float2 *__restrict__ gtab)
+{
+    __shared__ float2 xs[HIDEC_LDS_SAMPLES + 128];             // 2P sub-arrays of odd stride: at most S + 3*2P slots
+    typedef const float __attribute__((address_space(4))) *cfp;
+    const cfp taps = (cfp)taps_g;
+    const int t = threadIdx.x;
+    constexpr int NSUB = 1 << V1, PM = NSUB - 1, SUB = ((HIDEC_LDS_SAMPLES >> V1) + 2) | 1;
+    const long long n0 = (long long)blockIdx.x * Tn;             // first output of the tile
+    const long long u0 = n0 * D;                                 // its first sample
+    const int ns = (Tn - 1) * D + ntaps + NSUB;                  // samples touched, the last tap group rounded up (all staged:
+                                                                 // a zero tap times LDS garbage could be a NaN)
+    const long long last = n_in - 1;                             // n_in >= 1 (launcher)
+    for (int ub = t; ub < ns; ub += 256 * 8) {                   // eight independent loads in flight per lane
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long g = u0 + ub + 256 * j;
+            v[j] = x[g < last ? g : last];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int u = ub + 256 * j;
+            if (u < ns) xs[(u & PM) * SUB + (u >> V1)] = u0 + u < n_in ? v[j] : make_float2(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    if (2 * t >= Tn) return;
+    const float2 *xl = xs + ((2 * t * D) >> V1);                 // 2tD is a multiple of 2P
+    float2 a0 = make_float2(0.f, 0.f), a1 = a0;
+    auto mac = [&](float2 &acc, int k, float2 xv) {
+        if (CTAPS) {
+            const float hr = taps[2 * k], hi = taps[2 * k + 1];
+            acc.x = __builtin_fmaf(hr, xv.x, acc.x);
+            acc.x = __builtin_fmaf(-hi, xv.y, acc.x);
+            acc.y = __builtin_fmaf(hr, xv.y, acc.y);
+            acc.y = __builtin_fmaf(hi, xv.x, acc.y);
+        } else {
+            const float h = taps[k];
+            acc.x = __builtin_fmaf(h, xv.x, acc.x);
+            acc.y = __builtin_fmaf(h, xv.y, acc.y);
+        }
+    };
+    // k runs over [0, ntaps + D) in groups of 2P: inside a group the sub-array is a compile-time constant, so the
+    // LDS offsets are immediates.  Tap c[k] feeds the first output (k < ntaps), c[k-D] the second (k >= D):
+    // the tap table is zero padded by D in front and behind (host), so no conditions are needed.
+    const cfp t0 = taps + (CTAPS ? 2 : 1) * D;                   // c[k] at t0[k], zeros for -D <= k < 0 and ntaps <= k < ntaps + D
+    const int ngroups = (ntaps + D + NSUB - 1) >> V1;
+    for (int gk = 0; gk < ngroups; ++gk) {
+        const float2 *xg = xl + gk;
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            const int k = (gk << V1) + j;
+            const float2 xv = xg[j * SUB];
+            if (CTAPS) {
+                const float hr0 = t0[2 * k], hi0 = t0[2 * k + 1], hr1 = t0[2 * (k - D)], hi1 = t0[2 * (k - D) + 1];
+                a0.x = __builtin_fmaf(hr0, xv.x, a0.x); a0.x = __builtin_fmaf(-hi0, xv.y, a0.x);
+                a0.y = __builtin_fmaf(hr0, xv.y, a0.y); a0.y = __builtin_fmaf(hi0, xv.x, a0.y);
+                a1.x = __builtin_fmaf(hr1, xv.x, a1.x); a1.x = __builtin_fmaf(-hi1, xv.y, a1.x);
+                a1.y = __builtin_fmaf(hr1, xv.y, a1.y); a1.y = __builtin_fmaf(hi1, xv.x, a1.y);
+            } else {
+                const float h0 = t0[k], h1 = t0[k - D];
+                a0.x = __builtin_fmaf(h0, xv.x, a0.x); a0.y = __builtin_fmaf(h0, xv.y, a0.y);
+                a1.x = __builtin_fmaf(h1, xv.x, a1.x); a1.y = __builtin_fmaf(h1, xv.y, a1.y);
+            }
+        }
+    }
+    (void)mac;
+    const long long n = n0 + 2 * t;
+    if (gtab) {
+        if (n < n_out) a0 = cmul_ref(a0, gtab[n]);
+        if (n + 1 < n_out) a1 = cmul_ref(a1, gtab[n + 1]);
+    }
+    if (n + 1 < n_out && ((((uintptr_t)(y + n)) & 15) == 0)) {
+        *reinterpret_cast<float4 *>(y + n) = make_float4(a0.x, a0.y, a1.x, a1.y);
+    } else {
+        if (n < n_out) y[n] = a0;
+        if (n + 1 < n_out) y[n + 1] = a1;
+    }
+}
+
+int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in,
+                     float2 *y, long long n_out, const float2 *gtab, hipStream_t st)
+{
+    if (n_out <= 0) return GRHIP_OK;
+    if (!hidec_supported(decim, ntaps) || n_in < 1) return fail(GRHIP_EINVAL, "high-decimation FIR: unsupported shape");
+    const int Tn = hidec_outputs_per_tile(decim, ntaps);
+    const unsigned blocks = (unsigned)((n_out + Tn - 1) / Tn);
+    const int v1 = hidec_sub_log(decim);
+#define GRHIP_HIDEC(C, V)                                                                                            \
+    hipLaunchKernelGGL((fir_hidec_kernel<C, V>), dim3(blocks), dim3(256), 0, st, x, n_in, taps_padded, ntaps, decim, Tn, \
+                       n_out, y, gtab)
+    if (ctaps) {
+        switch (v1) { case 1: GRHIP_HIDEC(true, 1); break; case 2: GRHIP_HIDEC(true, 2); break; case 3: GRHIP_HIDEC(true, 3); break;
+                      case 4: GRHIP_HIDEC(true, 4); break; default: GRHIP_HIDEC(true, 5); break; }
+    } else {
+        switch (v1) { case 1: GRHIP_HIDEC(false, 1); break; case 2: GRHIP_HIDEC(false, 2); break; case 3: GRHIP_HIDEC(false, 3); break;
+                      case 4: GRHIP_HIDEC(false, 4); break; default: GRHIP_HIDEC(false, 5); break; }
+    }
+#undef GRHIP_HIDEC
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+// taps for launch_fir_hidec: correlation order, D zero taps in front and behind + one group of slack
+void hidec_pad_taps(const float *taps_corr, int ntaps, int tw, int decim, std::vector<float> &out)
+{
+    out.assign((size_t)(ntaps + 2 * decim + 64) * tw, 0.f);
+    for (int k = 0; k < ntaps * tw; ++k) out[(size_t)decim * tw + k] = taps_corr[k];
 }
 
 }  // namespace grhip

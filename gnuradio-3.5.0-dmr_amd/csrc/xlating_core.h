@@ -34,9 +34,9 @@ struct XlatingCore {
     bool use_tiled = false, premix = false;
     // FAST mode for the shapes the tiled kernel does not take (other decimations, long prototypes):
     // overlap-save engine (fft_kernels.hip) + rotator table multiply
-    bool use_ols = false, prefer_ols = false;
+    bool use_ols = false, prefer_ols = false, use_hidec = false;
     int ols_L = 0, ols_fold = 0;
-    DevBuf d_ols_tw, d_ols_H;
+    DevBuf d_ols_tw, d_ols_H, d_hidec_taps;
     DevBuf scratch_y;
     SchedBuf sched;                             // tile queue of the tiled kernel (one launch at a time per handle)
 

@@ -46,7 +46,9 @@ def test_fir_generic_mode_bit_exact(gpu, po, kind, ntaps, decim):
 @pytest.mark.parametrize("kind", ["ccf", "ccc"])
 @pytest.mark.parametrize("ntaps,decim", [(1, 1), (3, 1), (64, 1), (65, 2), (256, 4), (255, 4), (256, 1), (31, 8), (40, 3),
                                          (200, 3), (1500, 1), (2049, 5), (600, 8), (700, 16), (1100, 2),
-                                         (900, 4)])    # from (200, 3) on: overlap-save engine (folded inverse at D = 2..16)
+                                         (900, 4), (400, 20), (100, 5), (64, 7),
+                                         (2000, 50)])    # from (200, 3) on: overlap-save engine (folded inverse at D = 2..16), last four (and
+                                                         # (31, 8), (40, 3)): high-decimation direct kernel
 def test_fir_fast_mode_tolerance(gpu, po, kind, ntaps, decim):
     rng = np.random.default_rng(1000 + ntaps * 10 + decim)
     n = 5003           # not a multiple of the tile: exercises the ragged tail
@@ -470,7 +472,8 @@ def test_fir_random_shapes_fast_mode(gpu, po):
         assert err <= TOL * max(np.abs(ref).max(), 1e-3 * bound), (kind, ntaps, decim, n, err)
 
 
-@pytest.mark.parametrize("kind,ntaps,decim", [("ccf", 300, 1), ("ccc", 200, 3), ("ccf", 256, 4), ("ccc", 64, 2)])
+@pytest.mark.parametrize("kind,ntaps,decim", [("ccf", 300, 1), ("ccc", 200, 3), ("ccf", 256, 4), ("ccc", 64, 2), ("ccf", 100, 5),
+                                              ("ccc", 400, 20)])
 def test_fir_reads_nothing_past_the_guaranteed_items(gpu, po, kind, ntaps, decim):
     """the scheduler guarantees (n-1)*decim + ntaps input items (gr_sync_decimator.cc:46-50); whatever
     follows them (NaNs here) must not reach the outputs -- tiled kernel and overlap-save engine alike"""

@@ -131,17 +131,18 @@ report("fir_filter_ccf 256t D=1 FAST (overlap-save engine: 256 taps per phase)",
 blk5 = g.fir_filter_ccf(1, wl.lowpass_taps(128, 0.1, 1.0))
 report("fir_filter_ccf 128t D=1 FAST (tiled kernel)", timeit(lambda: blk5.work_device(n, x, y, st), reps=10), n, 16)
 
-# freq_xlating_fir_filter_ccc at a decimation the tiled kernel does not take: overlap-save engine + rotator
+# freq_xlating_fir_filter_ccc at decimations the tiled kernel does not take: high-decimation direct kernel + rotator
+# (tools/bench_decim.py compares it with the overlap-save engine shape by shape)
 n = 160_000_000
 x = torch.randn((n + 512, 2), device=dev)
 y = torch.empty((n // 20, 2), device=dev)
 blk = g.freq_xlating_fir_filter_ccc(20, wl.lowpass_taps(400, 0.02, 1.0).astype(np.complex64), c["center_freq"], c["fs"])
 def run_xl20():
     blk.reset(); blk.work_device(n // 20, x, y, st)
-report("freq_xlating_fir_filter_ccc 400t D=20 (overlap-save engine)", timeit(run_xl20, reps=10), n, 8.4)
+report("freq_xlating_fir_filter_ccc 400t D=20 (high-decimation direct kernel)", timeit(run_xl20, reps=10), n, 8.4)
 
 y16 = torch.empty((n // 16, 2), device=dev)
 blk16 = g.freq_xlating_fir_filter_ccc(16, wl.lowpass_taps(400, 0.02, 1.0).astype(np.complex64), c["center_freq"], c["fs"])
 def run_xl16():
     blk16.reset(); blk16.work_device(n // 16, x, y16, st)
-report("freq_xlating_fir_filter_ccc 400t D=16 (overlap-save engine, folded 256-point inverse)", timeit(run_xl16, reps=10), n, 8.5)
+report("freq_xlating_fir_filter_ccc 400t D=16 (high-decimation direct kernel)", timeit(run_xl16, reps=10), n, 8.5)
