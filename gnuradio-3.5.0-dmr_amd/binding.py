@@ -9,7 +9,7 @@ __all__ = [
     "MODE_FAST", "MODE_GENERIC",
     "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
-    "clock_recovery_mm_ff", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "stream_to_streams", "streams_to_stream",
+    "clock_recovery_mm_ff", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "stream_to_streams", "streams_to_stream",
     "fft_vcc", "fft_filter_ccc", "pfb_channelizer_ccf", "dmr_chain", "run_sync_block",
 ]
 
@@ -509,6 +509,43 @@ class unpack_k_bits_bb(_Block):
         L.grhip_unpack_k_bits_bb_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         n = _check(L.grhip_unpack_k_bits_bb_work(self._h, int(noutput_items), _ptr(x), _ptr(out)))
         return out[:n]
+
+
+class framer_sink_1(_Block):
+    """gr.framer_sink_1(msgq): header + payload extraction after the correlator's flag bit.
+    The reference inserts gr.message objects into `msgq`; here work() / work_device() collect them
+    and messages() returns (and removes) [(whitener_offset, payload bytes), ...] in order."""
+    _destroy = "grhip_framer_sink_1_destroy"
+
+    def __init__(self, device=0):
+        _Block.__init__(self)
+        L = lib()
+        L.grhip_framer_sink_1_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        _check(L.grhip_framer_sink_1_create(C.byref(self._h), int(device)))
+
+    def work(self, noutput_items, input_items):
+        x = np.ascontiguousarray(input_items, dtype=np.uint8)
+        L = lib()
+        L.grhip_framer_sink_1_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        return _check(L.grhip_framer_sink_1_work(self._h, int(noutput_items), _ptr(x)))
+
+    def work_device(self, noutput_items, d_in, stream=None):
+        L = lib()
+        L.grhip_framer_sink_1_work_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        return _check(L.grhip_framer_sink_1_work_device(self._h, int(noutput_items), _devptr(d_in), _stream(stream)))
+
+    def messages(self, stream=None):
+        L = lib()
+        L.grhip_framer_sink_1_message_count.argtypes = [C.c_void_p, C.c_void_p]
+        L.grhip_framer_sink_1_pop.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int]
+        n = _check(L.grhip_framer_sink_1_message_count(self._h, _stream(stream)))
+        buf = np.zeros(4096, dtype=np.uint8)
+        out = []
+        for _ in range(n):
+            woff = C.c_int(0)
+            ln = _check(L.grhip_framer_sink_1_pop(self._h, C.byref(woff), _ptr(buf), 4096))
+            out.append((woff.value, buf[:ln].tobytes()))
+        return out
 
 
 class _stream_adapter(_Block):

@@ -1,0 +1,403 @@
+// capi_framer.hip -- gr_framer_sink_1: kernels and C ABI.
+//
+// Reference: gnuradio-core/src/lib/general/gr_framer_sink_1.{h,cc}.  The block is a bit-serial state
+// machine (search for the correlator's flag bit .cc:105-117; shift 32 header bits, the flagged bit first
+// .cc:119-152; shift 8*len payload bits into bytes .cc:154-182), but its state only changes per PACKET:
+//   1. framer_pack_kernel     every input byte once: bit 0 and bit 1 of 32 items packed MSB-first into one
+//                             data word and one flag word (1 B read, 1/4 B written per item);
+//   2. framer_walk_kernel     one wavefront per stream walks packet to packet: 64 flag/data words (2048
+//                             items) live in the lanes' registers, the next flag is a ballot + clz, the
+//                             header a funnel shift of two data words; it emits message records and
+//                             payload jobs and carries the reference's state (partial header, partial
+//                             payload) across calls in device memory;
+//   3. framer_payload_kernel  the payload bytes of all jobs, one lane per byte, from the packed data words.
+// Messages (whitener offset = gr_message arg1, payload) collect in a device pool until the host fetches them.
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "grhip_internal.h"
+
+using namespace grhip;
+
+namespace grhip {
+
+enum { FR_SEARCH = 0, FR_HAVE_SYNC = 1, FR_HAVE_HEADER = 2 };   // gr_framer_sink_1.h:62
+
+struct FramerState {
+    int mode;
+    unsigned header;        // d_header
+    int hdr_cnt;            // d_headerbitlen_cnt
+    int pktlen;             // d_packetlen (bytes)
+    int woff;               // d_packet_whitener_offset
+    int bits_done;          // 8 * d_packetlen_cnt + d_packet_byte_index
+    unsigned msg_count;     // complete messages in msgs[]
+    unsigned pool_used;     // bytes of pool in use (including the open packet's reservation)
+    unsigned open_off;      // pool offset of the packet being filled
+    unsigned njobs;         // payload jobs of the current call
+    unsigned pad[6];
+};
+struct FramerMsg { unsigned woff, len, off, pad; };
+struct FramerJob { unsigned src_bit, nbits, dst_off, dst_bit; };
+
+// 4 items (one per byte, first item in the low byte) -> 4 bits, first item most significant
+__device__ inline unsigned nib(unsigned w, int bit)
+{
+    return ((((w >> bit) & 0x01010101u) * 0x08040201u) >> 24) & 0xfu;
+}
+
+__global__ void __launch_bounds__(256)
+framer_pack_kernel(const unsigned char *__restrict__ in, long long n, unsigned *__restrict__ F, unsigned *__restrict__ D,
+                   long long nwords_padded)
+{
+    for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < nwords_padded; w += (long long)gridDim.x * 256) {
+        const long long b = w << 5;
+        unsigned f = 0, d = 0;
+        if (b + 32 <= n && ((((uintptr_t)(in + b)) & 15) == 0)) {
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(in + b), q1 = *reinterpret_cast<const uint4 *>(in + b + 16);
+            const unsigned v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                d = (d << 4) | nib(v[i], 0);
+                f = (f << 4) | nib(v[i], 1);
+            }
+        } else {
+            for (int i = 0; i < 32; ++i) {
+                const unsigned c = b + i < n ? in[b + i] : 0u;
+                d = (d << 1) | (c & 1u);
+                f = (f << 1) | ((c >> 1) & 1u);
+            }
+        }
+        F[w] = f;
+        D[w] = d;
+    }
+}
+
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
+// One wavefront: the reference's state machine at packet granularity.  Every branch is wave-uniform and the
+// bookkeeping is 32-bit scalar arithmetic (a lone wave issues about one instruction every five cycles, so
+// the instruction count per packet is what the walk costs).  F and D hold nwords = ceil(n/32) words plus two
+// zero words.  n < 2^31.
+__global__ void __launch_bounds__(64)
+framer_walk_kernel(const unsigned *__restrict__ F, const unsigned *__restrict__ D, unsigned n, FramerState *S,
+                   FramerMsg *msgs, FramerJob *jobs)
+{
+    const unsigned lane = threadIdx.x;
+    int mode = uni(S->mode), hdr_cnt = uni(S->hdr_cnt), pktlen = uni(S->pktlen), woff = uni(S->woff), bits_done = uni(S->bits_done);
+    unsigned header = uni(S->header), msg_count = uni(S->msg_count), pool_used = uni(S->pool_used), open_off = uni(S->open_off);
+    unsigned njobs = 0;
+    const unsigned nwords = (n + 31u) >> 5;
+    unsigned pos = 0, wb = 0;                    // wb: first word of the register window
+    bool have_window = false;
+    unsigned Fw = 0, Dw = 0;
+
+    auto load_window = [&](unsigned w0) {
+        wb = w0;
+        have_window = true;
+        const unsigned wi = wb + lane;
+        Fw = wi < nwords ? F[wi] : 0u;
+        Dw = wi < nwords ? D[wi] : 0u;
+    };
+    // k (1..32) data bits starting at item s, first item most significant
+    auto bits_at = [&](unsigned s, int k) -> unsigned {
+        const unsigned i = s >> 5;
+        const int o = (int)(s & 31u);
+        unsigned d0, d1;
+        if (have_window && i >= wb && i + 1u < wb + 64u) {
+            const int li = (int)(i - wb);
+            d0 = __builtin_amdgcn_readlane(Dw, li);
+            d1 = __builtin_amdgcn_readlane(Dw, li + 1);
+        } else {
+            d0 = D[i]; d1 = D[i + 1];            // zero padded behind nwords
+        }
+        const unsigned long long w = ((unsigned long long)d0 << 32) | d1;
+        return (unsigned)((w << o) >> (64 - k));
+    };
+
+    for (;;) {
+        if (mode == FR_HAVE_SYNC) {
+            const unsigned avail = n - pos;
+            const unsigned need = 32u - (unsigned)hdr_cnt;
+            const int take = (int)(avail < need ? avail : need);
+            if (take > 0) {
+                const unsigned b = bits_at(pos, take);
+                header = take == 32 ? b : ((header << take) | b);
+                hdr_cnt += take;
+                pos += (unsigned)take;
+            }
+            if (hdr_cnt < 32) break;
+            if (((header >> 16) ^ (header & 0xffffu)) == 0) {          // header_ok(), .h:85-89
+                pktlen = (int)((header >> 16) & 0x0fffu);                // header_payload(), .h:91-98
+                woff = (int)((header >> 28) & 0xfu);
+                if (pktlen == 0) {                                       // .cc:137-146
+                    if (lane == 0) msgs[msg_count] = FramerMsg{(unsigned)woff, 0u, pool_used, 0u};
+                    ++msg_count;
+                    mode = FR_SEARCH;
+                } else {
+                    mode = FR_HAVE_HEADER;
+                    bits_done = 0;
+                    open_off = pool_used;
+                    pool_used += (unsigned)pktlen;
+                }
+            } else {
+                mode = FR_SEARCH;                                        // bad header, .cc:148-149
+            }
+        } else if (mode == FR_HAVE_HEADER) {
+            const unsigned avail = n - pos;
+            const unsigned rem = (unsigned)(8 * pktlen - bits_done);
+            const unsigned take = avail < rem ? avail : rem;
+            if (take > 0) {
+                if (lane == 0) jobs[njobs] = FramerJob{pos, take, open_off, (unsigned)bits_done};
+                ++njobs;
+                bits_done += (int)take;
+                pos += take;
+            }
+            if (bits_done < 8 * pktlen) break;
+            if (lane == 0) msgs[msg_count] = FramerMsg{(unsigned)woff, (unsigned)pktlen, open_off, 0u};
+            ++msg_count;
+            mode = FR_SEARCH;
+        } else {
+            // next flagged item at or after pos (.cc:109-116: the flagged item is the first header bit)
+            bool found = false;
+            while (pos < n) {
+                const unsigned w0 = pos >> 5;
+                if (!have_window || w0 < wb || w0 >= wb + 64u) load_window(w0);
+                const unsigned wi = wb + lane;
+                unsigned f = Fw;
+                if (wi < w0) f = 0u;
+                else if (wi == w0) f &= 0xffffffffu >> (pos & 31u);
+                const unsigned long long bal = __ballot(f != 0u);
+                if (bal == 0ull) { pos = (wb + 64u) << 5; continue; }
+                const int L = __ffsll((long long)bal) - 1;
+                const unsigned word = __builtin_amdgcn_readlane(f, L);
+                pos = ((wb + (unsigned)L) << 5) + (unsigned)__clz((int)word);
+                found = true;
+                break;
+            }
+            if (!found) break;                                           // pos >= n: still searching
+            // fast path: header and payload both inside this call -> one pass, no state round trip
+            if (pos + 32u <= n) {
+                const unsigned h = bits_at(pos, 32);
+                const unsigned len = (h >> 16) & 0x0fffu;
+                if (((h >> 16) ^ (h & 0xffffu)) != 0) { pos += 32u; continue; }
+                if (pos + 32u + 8u * len <= n) {
+                    if (lane == 0) {
+                        msgs[msg_count] = FramerMsg{(h >> 28) & 0xfu, len, pool_used, 0u};
+                        if (len) jobs[njobs] = FramerJob{pos + 32u, 8u * len, pool_used, 0u};
+                    }
+                    ++msg_count;
+                    if (len) ++njobs;
+                    pool_used += len;
+                    pos += 32u + 8u * len;
+                    continue;
+                }
+            }
+            mode = FR_HAVE_SYNC;                                         // enter_have_sync(), .cc:46-55
+            header = 0u;
+            hdr_cnt = 0;
+        }
+    }
+    if (lane == 0) {
+        S->mode = mode; S->header = header; S->hdr_cnt = hdr_cnt; S->pktlen = pktlen; S->woff = woff;
+        S->bits_done = bits_done; S->msg_count = msg_count; S->pool_used = pool_used; S->open_off = open_off;
+        S->njobs = njobs;
+    }
+}
+
+// payload bits -> bytes (.cc:158-162): one lane per packet byte; a byte shared with the previous call's
+// job keeps the bits that are already there
+__global__ void __launch_bounds__(256)
+framer_payload_kernel(const unsigned *__restrict__ D, const FramerState *S, const FramerJob *__restrict__ jobs,
+                      unsigned char *__restrict__ pool)
+{
+    const unsigned njobs = S->njobs;
+    for (unsigned j = blockIdx.x; j < njobs; j += gridDim.x) {
+        const FramerJob jb = jobs[j];
+        const unsigned first = jb.dst_bit >> 3, last = (jb.dst_bit + jb.nbits - 1) >> 3;
+        for (unsigned y = first + threadIdx.x; y <= last; y += 256) {
+            const unsigned b0 = max(8u * y, jb.dst_bit), b1 = min(8u * y + 8u, jb.dst_bit + jb.nbits);
+            const unsigned k = b1 - b0;                                  // 1..8 bits of this byte
+            const unsigned long long s = (unsigned long long)jb.src_bit + (b0 - jb.dst_bit);
+            const unsigned long long i = s >> 5;
+            const unsigned long long w = ((unsigned long long)D[i] << 32) | D[i + 1];
+            const unsigned v = (unsigned)((w << (s & 31)) >> (64 - k));
+            const unsigned sh = 8u * y + 8u - b1;                        // free low bits of the byte
+            unsigned char *dst = pool + jb.dst_off + y;
+            unsigned out = v << sh;
+            if (b0 > 8u * y) out |= *dst & ~((1u << (8u - (b0 - 8u * y))) - 1u);
+            *dst = (unsigned char)out;
+        }
+    }
+}
+
+// after a fetch: drop the delivered messages, move the open packet to the front of the pool
+__global__ void __launch_bounds__(256)
+framer_compact_kernel(FramerState *S, unsigned char *pool)
+{
+    __shared__ unsigned char keep[4096];
+    const bool open = S->mode == FR_HAVE_HEADER;
+    const unsigned off = S->open_off, nb = open ? ((unsigned)S->bits_done + 7u) >> 3 : 0u;
+    for (unsigned i = threadIdx.x; i < nb; i += 256) keep[i] = pool[off + i];
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < nb; i += 256) pool[i] = keep[i];
+    if (threadIdx.x == 0) {
+        S->msg_count = 0;
+        S->open_off = 0;
+        S->pool_used = open ? (unsigned)S->pktlen : 0u;
+    }
+}
+
+}  // namespace grhip
+
+struct grhip_framer_sink_1 : HandleBase {
+    DevBuf d_state, d_F, d_D, d_jobs, d_msgs, d_pool;
+    size_t msg_bound = 0, pool_bound = 4096;     // upper bounds of what un-fetched calls can have produced
+    // host copy of the last fetch
+    std::vector<FramerMsg> h_msgs;
+    std::vector<unsigned char> h_pool;
+    size_t next_msg = 0;
+
+    int grow(DevBuf &b, size_t keep_bytes, size_t want, hipStream_t st)
+    {
+        if (want <= b.cap) return GRHIP_OK;
+        DevBuf nb;
+        int rc = nb.reserve(want * 2);
+        if (rc) return rc;
+        if (b.p && keep_bytes) GRHIP_HIP(hipMemcpyAsync(nb.p, b.p, std::min(keep_bytes, b.cap), hipMemcpyDeviceToDevice, st));
+        GRHIP_HIP(hipStreamSynchronize(st));
+        b.release();
+        b = nb;
+        return GRHIP_OK;
+    }
+};
+
+int grhip_framer_sink_1_create(grhip_framer_sink_1 **h, int device)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    auto *b = new (std::nothrow) grhip_framer_sink_1();
+    if (!b) return fail(GRHIP_ENOMEM, "alloc");
+    int rc = b->init_device(device);
+    if (!rc) rc = b->d_state.reserve(sizeof(FramerState));
+    if (!rc && hipMemset(b->d_state.p, 0, sizeof(FramerState)) != hipSuccess) rc = fail(GRHIP_ERUNTIME, "hipMemset failed");   // enter_search(), .cc:84
+    if (rc) { grhip_framer_sink_1_destroy(b); return rc; }
+    *h = b;
+    return GRHIP_OK;
+}
+
+void grhip_framer_sink_1_destroy(grhip_framer_sink_1 *h)
+{
+    if (!h) return;
+    (void)h->bind();
+    h->d_state.release(); h->d_F.release(); h->d_D.release(); h->d_jobs.release(); h->d_msgs.release(); h->d_pool.release();
+    h->destroy_base();
+    delete h;
+}
+
+int grhip_framer_sink_1_work_device(grhip_framer_sink_1 *h, int noutput_items, const unsigned char *d_in, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative item count");
+    if (noutput_items == 0) return 0;
+    if (!d_in) return fail(GRHIP_EINVAL, "null buffer");
+    int rc = h->bind();
+    if (rc) return rc;
+    hipStream_t st = h->pick(stream);
+    const long long n = noutput_items, nwords = (n + 31) >> 5, nwp = nwords + 2;
+    if ((rc = h->d_F.reserve((size_t)nwp * 4))) return rc;
+    if ((rc = h->d_D.reserve((size_t)nwp * 4))) return rc;
+    if ((rc = h->d_jobs.reserve((size_t)(n / 32 + 4) * sizeof(FramerJob)))) return rc;
+    // every packet costs at least 32 items; payload bytes cost 8 items each; one packet of up to 4095 bytes may be open
+    if ((rc = h->grow(h->d_msgs, h->msg_bound * sizeof(FramerMsg), (h->msg_bound + (size_t)n / 32 + 4) * sizeof(FramerMsg), st))) return rc;
+    if ((rc = h->grow(h->d_pool, h->pool_bound, h->pool_bound + (size_t)n / 8 + 4096 + 16, st))) return rc;
+    h->msg_bound += (size_t)n / 32 + 2;
+    h->pool_bound += (size_t)n / 8 + 4096;
+    if (h->pool_bound > 0xf0000000ull) return fail(GRHIP_EINVAL, "framer_sink_1: fetch the messages before queueing more than 4 GiB of payload");
+
+    const unsigned pack_blocks = (unsigned)std::min<long long>((nwp + 255) / 256, 8192);
+    hipLaunchKernelGGL(framer_pack_kernel, dim3(pack_blocks), dim3(256), 0, st, d_in, n, h->d_F.as<unsigned>(),
+                       h->d_D.as<unsigned>(), nwp);
+    hipLaunchKernelGGL(framer_walk_kernel, dim3(1), dim3(64), 0, st, h->d_F.as<unsigned>(), h->d_D.as<unsigned>(), (unsigned)n,
+                       h->d_state.as<FramerState>(), h->d_msgs.as<FramerMsg>(), h->d_jobs.as<FramerJob>());
+    const unsigned pay_blocks = (unsigned)std::min<long long>(n / 256 + 1, 2048);
+    hipLaunchKernelGGL(framer_payload_kernel, dim3(pay_blocks), dim3(256), 0, st, h->d_D.as<unsigned>(),
+                       h->d_state.as<FramerState>(), h->d_jobs.as<FramerJob>(), h->d_pool.as<unsigned char>());
+    GRHIP_HIP(hipGetLastError());
+    return noutput_items;                        // a sink: consumes everything (.cc:189)
+}
+
+// brings the complete messages of all calls so far to the host and empties the device queue
+static int framer_fetch(grhip_framer_sink_1 *h, hipStream_t st)
+{
+    FramerState s;
+    GRHIP_HIP(hipMemcpyAsync(&s, h->d_state.p, sizeof(s), hipMemcpyDeviceToHost, st));
+    GRHIP_HIP(hipStreamSynchronize(st));
+    // drop what the caller has already popped
+    h->h_msgs.erase(h->h_msgs.begin(), h->h_msgs.begin() + h->next_msg);
+    h->next_msg = 0;
+    if (s.msg_count) {
+        std::vector<FramerMsg> m(s.msg_count);
+        std::vector<unsigned char> p(s.pool_used ? s.pool_used : 1);
+        GRHIP_HIP(hipMemcpyAsync(m.data(), h->d_msgs.p, m.size() * sizeof(FramerMsg), hipMemcpyDeviceToHost, st));
+        if (s.pool_used) GRHIP_HIP(hipMemcpyAsync(p.data(), h->d_pool.p, s.pool_used, hipMemcpyDeviceToHost, st));
+        GRHIP_HIP(hipStreamSynchronize(st));
+        // append: payloads re-based onto the host pool
+        if (h->h_msgs.empty()) h->h_pool.clear();
+        const unsigned base = (unsigned)h->h_pool.size();
+        for (auto &r : m) {
+            FramerMsg q = r;
+            q.off = (unsigned)h->h_pool.size();
+            h->h_pool.insert(h->h_pool.end(), p.begin() + r.off, p.begin() + r.off + r.len);
+            h->h_msgs.push_back(q);
+        }
+        (void)base;
+    }
+    if (h->d_pool.p) {
+        hipLaunchKernelGGL(framer_compact_kernel, dim3(1), dim3(256), 0, st, h->d_state.as<FramerState>(),
+                           h->d_pool.as<unsigned char>());
+        GRHIP_HIP(hipGetLastError());
+    }
+    h->msg_bound = 0;
+    h->pool_bound = 4096;
+    return GRHIP_OK;
+}
+
+int grhip_framer_sink_1_message_count(grhip_framer_sink_1 *h, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    int rc = h->bind();
+    if (rc) return rc;
+    if ((rc = framer_fetch(h, h->pick(stream)))) return rc;
+    return (int)(h->h_msgs.size() - h->next_msg);
+}
+
+int grhip_framer_sink_1_pop(grhip_framer_sink_1 *h, int *whitener_offset, unsigned char *payload, int capacity)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (h->next_msg >= h->h_msgs.size()) return fail(GRHIP_EINVAL, "framer_sink_1: no message (call message_count first)");
+    const FramerMsg &m = h->h_msgs[h->next_msg];
+    if ((int)m.len > capacity || (m.len && !payload)) return fail(GRHIP_EINVAL, "framer_sink_1: payload buffer too small (4096 always fits)");
+    if (whitener_offset) *whitener_offset = (int)m.woff;
+    if (m.len) memcpy(payload, h->h_pool.data() + m.off, m.len);
+    ++h->next_msg;
+    return (int)m.len;
+}
+
+int grhip_framer_sink_1_work(grhip_framer_sink_1 *h, int noutput_items, const unsigned char *in)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative item count");
+    if (noutput_items == 0) return 0;
+    if (!in) return fail(GRHIP_EINVAL, "null buffer");
+    int rc = h->bind();
+    if (rc) return rc;
+    if ((rc = h->stage_in.reserve((size_t)noutput_items))) return rc;
+    hipStream_t st = h->own_stream;
+    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, (size_t)noutput_items, hipMemcpyHostToDevice, st));
+    rc = grhip_framer_sink_1_work_device(h, noutput_items, h->stage_in.as<unsigned char>(), st);
+    if (rc < 0) return rc;
+    GRHIP_HIP(hipStreamSynchronize(st));
+    return noutput_items;
+}

@@ -7,6 +7,7 @@
 //   gr_sync_decimator   gnuradio-core/src/lib/runtime/gr_sync_decimator.cc:38-68
 //   gr_sync_interpolator gnuradio-core/src/lib/runtime/gr_sync_interpolator.cc:30-75
 //   gr_io_signature     gnuradio-core/src/lib/runtime/gr_io_signature.h
+//   gr_message / gr_msg_queue  gnuradio-core/src/lib/runtime/gr_message.h:36-81, gr_msg_queue.h:36-86
 // When building against a real GNU Radio 3.5 tree define GRHIP_USE_GNURADIO and
 // the real headers are used instead (the wrappers only rely on what is here).
 #pragma once
@@ -14,6 +15,8 @@
 #ifdef GRHIP_USE_GNURADIO
 #include <gr_block.h>
 #include <gr_io_signature.h>
+#include <gr_message.h>
+#include <gr_msg_queue.h>
 #include <gr_sync_block.h>
 #include <gr_sync_decimator.h>
 #include <gr_sync_interpolator.h>
@@ -21,6 +24,9 @@
 
 #include <cmath>
 #include <complex>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -165,5 +171,67 @@ public:
         return r;
     }
 };
+
+// runtime/gr_message.h: type, two numeric arguments and a byte string
+class gr_message {
+    long d_type;
+    double d_arg1, d_arg2;
+    std::vector<unsigned char> d_buf;
+public:
+    gr_message(long type, double arg1, double arg2, size_t length) : d_type(type), d_arg1(arg1), d_arg2(arg2), d_buf(length) {}
+    long type() const { return d_type; }
+    double arg1() const { return d_arg1; }
+    double arg2() const { return d_arg2; }
+    unsigned char *msg() { return d_buf.data(); }
+    size_t length() const { return d_buf.size(); }
+    std::string to_string() const { return std::string(d_buf.begin(), d_buf.end()); }
+};
+typedef boost::shared_ptr<gr_message> gr_message_sptr;
+inline gr_message_sptr gr_make_message(long type = 0, double arg1 = 0, double arg2 = 0, size_t length = 0)
+{
+    return gr_message_sptr(new gr_message(type, arg1, arg2, length));
+}
+
+// runtime/gr_msg_queue.h: thread-safe FIFO; insert_tail blocks while a bounded queue is full
+class gr_msg_queue {
+    std::deque<gr_message_sptr> d_q;
+    std::mutex d_m;
+    std::condition_variable d_not_empty, d_not_full;
+    unsigned d_limit;
+public:
+    explicit gr_msg_queue(unsigned limit = 0) : d_limit(limit) {}
+    void insert_tail(gr_message_sptr msg)
+    {
+        std::unique_lock<std::mutex> l(d_m);
+        d_not_full.wait(l, [&] { return d_limit == 0 || d_q.size() < d_limit; });
+        d_q.push_back(msg);
+        d_not_empty.notify_one();
+    }
+    gr_message_sptr delete_head()
+    {
+        std::unique_lock<std::mutex> l(d_m);
+        d_not_empty.wait(l, [&] { return !d_q.empty(); });
+        gr_message_sptr m = d_q.front();
+        d_q.pop_front();
+        d_not_full.notify_one();
+        return m;
+    }
+    gr_message_sptr delete_head_nowait()
+    {
+        std::unique_lock<std::mutex> l(d_m);
+        if (d_q.empty()) return gr_message_sptr();
+        gr_message_sptr m = d_q.front();
+        d_q.pop_front();
+        d_not_full.notify_one();
+        return m;
+    }
+    void flush() { while (delete_head_nowait()) {} }
+    bool empty_p() { std::unique_lock<std::mutex> l(d_m); return d_q.empty(); }
+    bool full_p() { std::unique_lock<std::mutex> l(d_m); return d_limit != 0 && d_q.size() >= d_limit; }
+    unsigned count() { std::unique_lock<std::mutex> l(d_m); return (unsigned)d_q.size(); }
+    unsigned limit() const { return d_limit; }
+};
+typedef boost::shared_ptr<gr_msg_queue> gr_msg_queue_sptr;
+inline gr_msg_queue_sptr gr_make_msg_queue(unsigned limit = 0) { return gr_msg_queue_sptr(new gr_msg_queue(limit)); }
 
 #endif  // GRHIP_USE_GNURADIO

@@ -18,6 +18,7 @@
 // output_multiple, which the flowgraph honours when it sizes buffers
 // (runtime/gr_flat_flowgraph.cc:102-104,118).
 #pragma once
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -299,6 +300,44 @@ public:
 inline grhip_unpack_k_bits_bb_sptr grhip_make_unpack_k_bits_bb(unsigned k, int device = 0)
 {
     return gnuradio::get_initial_sptr(new grhip_unpack_k_bits_bb_blk(k, device));
+}
+
+// gr_framer_sink_1 (general/gr_framer_sink_1.h:34-107): same constructor argument, same messages in the same queue
+class grhip_framer_sink_1_blk;
+typedef boost::shared_ptr<grhip_framer_sink_1_blk> grhip_framer_sink_1_sptr;
+class grhip_framer_sink_1_blk : public gr_sync_block {
+    grhip_framer_sink_1 *d_h = nullptr;
+    gr_msg_queue_sptr d_target_queue;
+    std::vector<unsigned char> d_buf;
+    grhip_framer_sink_1_blk(gr_msg_queue_sptr target_queue, int device)
+        : gr_sync_block("framer_sink_1", gr_make_io_signature(1, 1, sizeof(unsigned char)), gr_make_io_signature(0, 0, 0)),
+          d_target_queue(target_queue), d_buf(4096)
+    {
+        grhip_detail::check(grhip_framer_sink_1_create(&d_h, device));
+    }
+    friend grhip_framer_sink_1_sptr grhip_make_framer_sink_1(gr_msg_queue_sptr, int);
+public:
+    ~grhip_framer_sink_1_blk() { grhip_framer_sink_1_destroy(d_h); }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &) override
+    {
+        int r = grhip_framer_sink_1_work(d_h, n, (const unsigned char *)in[0]);
+        grhip_detail::check(r);
+        int m = grhip_framer_sink_1_message_count(d_h, nullptr);
+        grhip_detail::check(m);
+        for (int i = 0; i < m; i++) {
+            int woff = 0;
+            int len = grhip_framer_sink_1_pop(d_h, &woff, d_buf.data(), (int)d_buf.size());
+            grhip_detail::check(len);
+            gr_message_sptr msg = gr_make_message(0, woff, 0, len);      // .cc:140-141, 168-170
+            if (len) memcpy(msg->msg(), d_buf.data(), len);
+            d_target_queue->insert_tail(msg);
+        }
+        return r;
+    }
+};
+inline grhip_framer_sink_1_sptr grhip_make_framer_sink_1(gr_msg_queue_sptr target_queue, int device = 0)
+{
+    return gnuradio::get_initial_sptr(new grhip_framer_sink_1_blk(target_queue, device));
 }
 
 class grhip_correlate_access_code_bb_blk;

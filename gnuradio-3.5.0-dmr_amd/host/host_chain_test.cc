@@ -5,6 +5,7 @@
 // that drives it and writes each stage's output for comparison with the oracle.
 //
 // usage: host_chain_test <dir> <mode: chain|errors>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -74,6 +75,24 @@ int main(int argc, char **argv)
         std::vector<float> dc(1, ps->dc_offset());
         std::vector<unsigned char> dcb((unsigned char *)dc.data(), (unsigned char *)dc.data() + 4);
         dump(dir + "/dc.f32", dcb);
+        // correlator output -> framer_sink_1 -> message queue (pkt.py:143-147), 4000 items per work() call
+        std::vector<unsigned char> fl = slurp<unsigned char>(dir + "/flagged.u8");
+        gr_msg_queue_sptr q = gr_make_msg_queue();
+        grhip_framer_sink_1_sptr fs = grhip_make_framer_sink_1(q);
+        for (size_t a = 0; a < fl.size(); a += 4000) {
+            gr_vector_const_void_star in(1, fl.data() + a);
+            gr_vector_void_star out;
+            int n = (int)std::min<size_t>(4000, fl.size() - a);
+            if (fs->work(n, in, out) != n) { std::cerr << "framer work\n"; return 1; }
+        }
+        std::vector<unsigned char> flat;
+        while (gr_message_sptr m = q->delete_head_nowait()) {
+            flat.push_back((unsigned char)m->arg1());
+            flat.push_back((unsigned char)(m->length() & 0xff));
+            flat.push_back((unsigned char)(m->length() >> 8));
+            flat.insert(flat.end(), m->msg(), m->msg() + m->length());
+        }
+        dump(dir + "/messages.bin", flat);
         std::cout << "widened ok\n";
         return 0;
     }

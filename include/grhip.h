@@ -260,6 +260,34 @@ GRHIP_API int grhip_unpack_k_bits_bb_work_device(grhip_unpack_k_bits_bb *h, int 
                                                  const unsigned char *d_in, unsigned char *d_out, void *stream);
 
 /* ======================================================================
+ * gr_framer_sink_1  (the consumer of the correlator's flag bit)
+ *   replaces gr_make_framer_sink_1(gr_msg_queue_sptr target_queue)
+ *   general/gr_framer_sink_1.h:62-98, general/gr_framer_sink_1.cc:34-66 (states), 90-190 (work):
+ *   items carry the data bit in bit 0 and "first bit after the access code" in bit 1; the flagged
+ *   item starts a 32-bit header (two equal 16-bit words: 4 bits whitener offset, 12 bits payload
+ *   length), followed by 8 * length payload bits, most significant bit of each byte first.  Flags
+ *   inside a header or payload are ignored; a header whose halves differ returns to the search.
+ * The reference inserts gr_message(type 0, arg1 = whitener offset, arg2 = 0, length) into its queue
+ * from inside work(); here work()/work_device() collect the messages on the device and the caller
+ * moves them into its queue with message_count() + pop():
+ *   message_count  waits for the queued work on `stream`, brings every complete message to the host
+ *                  and returns how many are waiting to be popped;
+ *   pop            next message in order: returns the payload length (0..4095), stores arg1 in
+ *                  *whitener_offset and the payload in `payload` (capacity >= 4096 always fits).
+ * work() returns noutput_items (a sink consumes everything, .cc:189).  State (partial header,
+ * partial payload) carries across calls exactly as in the reference.
+ * ====================================================================== */
+typedef struct grhip_framer_sink_1 grhip_framer_sink_1;
+GRHIP_API int grhip_framer_sink_1_create(grhip_framer_sink_1 **h, int device);
+GRHIP_API void grhip_framer_sink_1_destroy(grhip_framer_sink_1 *h);
+GRHIP_API int grhip_framer_sink_1_work(grhip_framer_sink_1 *h, int noutput_items, const unsigned char *in);
+GRHIP_API int grhip_framer_sink_1_work_device(grhip_framer_sink_1 *h, int noutput_items, const unsigned char *d_in,
+                                              void *stream);
+GRHIP_API int grhip_framer_sink_1_message_count(grhip_framer_sink_1 *h, void *stream);
+GRHIP_API int grhip_framer_sink_1_pop(grhip_framer_sink_1 *h, int *whitener_offset, unsigned char *payload,
+                                      int capacity);
+
+/* ======================================================================
  * gr_stream_to_streams / gr_streams_to_stream  (the adapters either side of the
  * channeliser)
  *   replace gr_make_stream_to_streams(size_t item_size, size_t nstreams) and

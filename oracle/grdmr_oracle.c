@@ -518,6 +518,89 @@ ORC_API void orc_unpack_k_bits_bb(unsigned k, const unsigned char *in, unsigned 
 }
 
 /* ------------------------------------------------------------------ */
+/* gr_framer_sink_1 (general/gr_framer_sink_1.cc:34-66 state entries,     */
+/* 90-190 work; general/gr_framer_sink_1.h:62-98 state, header_ok,       */
+/* header_payload).  Messages are appended to caller arrays instead of    */
+/* a gr_msg_queue: msg_woff[i] (gr_message arg1), msg_len[i], payload     */
+/* bytes back to back in `pool`.  Returns the number of messages added.   */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int state;                       /* 0 search, 1 have sync, 2 have header */
+    unsigned int header;
+    int headerbitlen_cnt;
+    unsigned char packet[4096];
+    unsigned char packet_byte;
+    int packet_byte_index;
+    int packetlen;
+    int packet_whitener_offset;
+    int packetlen_cnt;
+} orc_framer_state;
+
+ORC_API size_t orc_framer_state_size(void) { return sizeof(orc_framer_state); }
+
+ORC_API void orc_framer_sink_1_init(orc_framer_state *s)
+{
+    memset(s, 0, sizeof(*s));
+    s->state = 0;                    /* enter_search() in the constructor, .cc:84 */
+}
+
+ORC_API int orc_framer_sink_1_work(orc_framer_state *s, const unsigned char *in, int noutput_items, int *msg_woff,
+                                   int *msg_len, unsigned char *pool, size_t *pool_used)
+{
+    int count = 0, nmsg = 0;
+    while (count < noutput_items) {
+        switch (s->state) {
+        case 0:
+            while (count < noutput_items) {
+                if (in[count] & 0x2) {               /* the flagged item is NOT consumed here */
+                    s->state = 1; s->header = 0; s->headerbitlen_cnt = 0;
+                    break;
+                }
+                count++;
+            }
+            break;
+        case 1:
+            while (count < noutput_items) {
+                s->header = (s->header << 1) | (in[count++] & 0x1);
+                if (++s->headerbitlen_cnt == 32) {
+                    if ((((s->header >> 16) ^ (s->header & 0xffff)) == 0)) {
+                        s->state = 2;
+                        s->packetlen = (s->header >> 16) & 0x0fff;
+                        s->packet_whitener_offset = (s->header >> 28) & 0x000f;
+                        s->packetlen_cnt = 0; s->packet_byte = 0; s->packet_byte_index = 0;
+                        if (s->packetlen == 0) {
+                            msg_woff[nmsg] = s->packet_whitener_offset; msg_len[nmsg] = 0; nmsg++;
+                            s->state = 0;
+                        }
+                    } else {
+                        s->state = 0;
+                    }
+                    break;
+                }
+            }
+            break;
+        default:
+            while (count < noutput_items) {
+                s->packet_byte = (unsigned char)((s->packet_byte << 1) | (in[count++] & 0x1));
+                if (s->packet_byte_index++ == 7) {
+                    s->packet[s->packetlen_cnt++] = s->packet_byte;
+                    s->packet_byte_index = 0;
+                    if (s->packetlen_cnt == s->packetlen) {
+                        msg_woff[nmsg] = s->packet_whitener_offset; msg_len[nmsg] = s->packetlen_cnt; nmsg++;
+                        memcpy(pool + *pool_used, s->packet, (size_t)s->packetlen_cnt);
+                        *pool_used += (size_t)s->packetlen_cnt;
+                        s->state = 0;
+                        break;
+                    }
+                }
+            }
+            break;
+        }
+    }
+    return nmsg;
+}
+
+/* ------------------------------------------------------------------ */
 /* gr_count_bits64 (general/gr_count_bits.cc:75-93)                     */
 /* ------------------------------------------------------------------ */
 static unsigned count_bits32(unsigned x)

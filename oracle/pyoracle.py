@@ -240,6 +240,37 @@ class PagerSlicer:
         return np.float32(self.avg.value)
 
 
+class FramerSink1:
+    """gr_framer_sink_1: state carried across work() calls; work() returns the messages
+    [(whitener_offset, payload bytes), ...] the reference would have queued during the call"""
+
+    def __init__(self):
+        o = _need()
+        o.orc_framer_state_size.restype = C.c_size_t
+        self.state = C.create_string_buffer(o.orc_framer_state_size())
+        o.orc_framer_sink_1_init.argtypes = [C.c_void_p]
+        o.orc_framer_sink_1_init(self.state)
+
+    def work(self, x):
+        o = _need()
+        x = np.ascontiguousarray(x, dtype=np.uint8)
+        cap = len(x) // 32 + 2
+        woff = np.zeros(cap, dtype=np.int32)
+        mlen = np.zeros(cap, dtype=np.int32)
+        pool = np.zeros(len(x) // 8 + 4096, dtype=np.uint8)
+        used = C.c_size_t(0)
+        o.orc_framer_sink_1_work.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.POINTER(C.c_size_t)]
+        o.orc_framer_sink_1_work.restype = C.c_int
+        n = o.orc_framer_sink_1_work(self.state, x.ctypes.data, len(x), woff.ctypes.data, mlen.ctypes.data,
+                                     pool.ctypes.data, C.byref(used))
+        out, off = [], 0
+        for i in range(n):
+            out.append((int(woff[i]), pool[off:off + mlen[i]].tobytes()))
+            off += int(mlen[i])
+        return out
+
+
 def unpack_k_bits_bb(k, x):
     o = _need()
     x = np.ascontiguousarray(x, dtype=np.uint8)

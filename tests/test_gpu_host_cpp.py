@@ -69,6 +69,9 @@ def test_cpp_widened_blocks_through_block_interface(exe, tmp_path, po, wl):
     taps = (wl.lowpass_taps(300, 0.1, 1.0) * np.exp(1j * 0.02 * np.arange(300))).astype(np.complex64)
     soft = (rng.integers(0, 4, 70_001) * 2.0 - 3.0 + 0.4 + 0.3 * rng.standard_normal(70_001)).astype(np.float32)
     x.tofile(tmp_path / "x.c64"); taps.tofile(tmp_path / "taps.c64"); soft.tofile(tmp_path / "soft.f32")
+    from test_gpu_framer import make_stream
+    flagged = make_stream(rng, 150_001, 150, 90)
+    flagged.tofile(tmp_path / "flagged.u8")
     r = subprocess.run([exe, str(tmp_path), "widened"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     y = np.fromfile(tmp_path / "fftfilt.c64", np.complex64)
@@ -83,3 +86,6 @@ def test_cpp_widened_blocks_through_block_interface(exe, tmp_path, po, wl):
     sym = o.work(soft)
     assert np.array_equal(bits, po.unpack_k_bits_bb(2, sym))
     assert np.fromfile(tmp_path / "dc.f32", np.float32)[0].tobytes() == o.dc_offset().tobytes()
+    # framer_sink_1 -> gr_msg_queue: arg1 = whitener offset, payload bytes, in order
+    flat = b"".join(bytes([w, len(pl) & 0xFF, len(pl) >> 8]) + pl for w, pl in po.FramerSink1().work(flagged))
+    assert (tmp_path / "messages.bin").read_bytes() == flat and len(flat) > 1000
