@@ -10,7 +10,7 @@ __all__ = [
     "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
     "clock_recovery_mm_ff", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "stream_to_streams", "streams_to_stream",
-    "fft_vcc", "fft_filter_ccc", "pfb_channelizer_ccf", "dmr_chain", "run_sync_block",
+    "fft_vcc", "fft_filter_ccc", "pfb_channelizer_ccf", "pfb_decimator_ccf", "dmr_chain", "run_sync_block",
 ]
 
 MODE_FAST = 0
@@ -768,6 +768,46 @@ class pfb_channelizer_ccf(_Block):
         return _check(L.grhip_pfb_channelizer_ccf_general_work_device(
             self._h, int(noutput_items), _devptr(d_in), int(stream_stride_items), _devptr(d_out),
             _stream(stream)))
+
+
+class pfb_decimator_ccf(_Block):
+    """gr.pfb_decimator_ccf(decim, taps, channel)"""
+    _destroy = "grhip_pfb_decimator_ccf_destroy"
+
+    def __init__(self, decim, taps, channel=0, device=0):
+        _Block.__init__(self)
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        self.decim = int(decim)
+        L = lib()
+        L.grhip_pfb_decimator_ccf_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint, C.c_void_p, C.c_size_t,
+                                                     C.c_uint, C.c_int]
+        _check(L.grhip_pfb_decimator_ccf_create(C.byref(self._h), self.decim, _ptr(t), len(t), int(channel),
+                                                int(device)))
+
+    def set_taps(self, taps):
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        L = lib()
+        L.grhip_pfb_decimator_ccf_set_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        _check(L.grhip_pfb_decimator_ccf_set_taps(self._h, _ptr(t), len(t)))
+
+    def history(self):
+        return _check(lib().grhip_pfb_decimator_ccf_history(self._h))
+
+    def work(self, noutput_items, streams):
+        arrs = [np.ascontiguousarray(s, dtype=np.complex64) for s in streams]
+        ptrs = (C.c_void_p * self.decim)(*[a.ctypes.data for a in arrs])
+        out = np.zeros(max(noutput_items, 1), dtype=np.complex64)
+        L = lib()
+        L.grhip_pfb_decimator_ccf_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        n = _check(L.grhip_pfb_decimator_ccf_work(self._h, int(noutput_items), ptrs, _ptr(out)))
+        return out[:n]
+
+    def work_device(self, noutput_items, d_in, stream_stride_items, d_out, stream=None):
+        L = lib()
+        L.grhip_pfb_decimator_ccf_work_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                          C.c_void_p]
+        return _check(L.grhip_pfb_decimator_ccf_work_device(self._h, int(noutput_items), _devptr(d_in),
+                                                            int(stream_stride_items), _devptr(d_out), _stream(stream)))
 
 
 # ----------------------------------------------------------------------------

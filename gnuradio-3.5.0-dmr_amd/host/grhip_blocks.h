@@ -440,6 +440,40 @@ inline grhip_fft_filter_ccc_sptr grhip_make_fft_filter_ccc(int decimation, const
     return gnuradio::get_initial_sptr(new grhip_fft_filter_ccc_blk(decimation, taps, device));
 }
 
+// gr_pfb_decimator_ccf (filter/gr_pfb_decimator_ccf.h:100-140)
+class grhip_pfb_decimator_ccf_blk;
+typedef boost::shared_ptr<grhip_pfb_decimator_ccf_blk> grhip_pfb_decimator_ccf_sptr;
+class grhip_pfb_decimator_ccf_blk : public gr_sync_block {
+    grhip_pfb_decimator_ccf *d_h = nullptr;
+    grhip_pfb_decimator_ccf_blk(unsigned decim, const std::vector<float> &taps, unsigned channel, int device)
+        : gr_sync_block("pfb_decimator_ccf", gr_make_io_signature(decim, decim, sizeof(gr_complex)),
+                        gr_make_io_signature(1, 1, sizeof(gr_complex)))
+    {
+        grhip_detail::check(grhip_pfb_decimator_ccf_create(&d_h, decim, taps.data(), taps.size(), channel, device));
+        set_history(grhip_pfb_decimator_ccf_history(d_h));           // .cc:108
+        set_output_multiple(1024);
+    }
+    friend grhip_pfb_decimator_ccf_sptr grhip_make_pfb_decimator_ccf(unsigned, const std::vector<float> &, unsigned, int);
+public:
+    ~grhip_pfb_decimator_ccf_blk() { grhip_pfb_decimator_ccf_destroy(d_h); }
+    void set_taps(const std::vector<float> &taps)
+    {
+        grhip_detail::check(grhip_pfb_decimator_ccf_set_taps(d_h, taps.data(), taps.size()));
+        set_history(grhip_pfb_decimator_ccf_history(d_h));
+    }
+    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        int r = grhip_pfb_decimator_ccf_work(d_h, n, in.data(), out[0]);
+        grhip_detail::check(r);
+        return r;
+    }
+};
+inline grhip_pfb_decimator_ccf_sptr grhip_make_pfb_decimator_ccf(unsigned decim, const std::vector<float> &taps,
+                                                                 unsigned channel = 0, int device = 0)
+{
+    return gnuradio::get_initial_sptr(new grhip_pfb_decimator_ccf_blk(decim, taps, channel, device));
+}
+
 class grhip_pfb_channelizer_ccf_blk;
 typedef boost::shared_ptr<grhip_pfb_channelizer_ccf_blk> grhip_pfb_channelizer_ccf_sptr;
 class grhip_pfb_channelizer_ccf_blk : public gr_block {

@@ -260,6 +260,29 @@ GRHIP_API int grhip_unpack_k_bits_bb_work_device(grhip_unpack_k_bits_bb *h, int 
                                                  const unsigned char *d_in, unsigned char *d_out, void *stream);
 
 /* ======================================================================
+ * gr_pfb_decimator_ccf  (polyphase decimator, one output channel)
+ *   replaces gr_make_pfb_decimator_ccf(unsigned decim, const std::vector<float> &taps,
+ *                                      unsigned channel)
+ *   filter/gr_pfb_decimator_ccf.h:100-140, filter/gr_pfb_decimator_ccf.cc:43-68 (constructor),
+ *   77-111 (set_taps: filter j gets taps[j + t*decim], history = taps per filter), 130-180 (work:
+ *   `decim` input streams, stream s feeds filter decim-1-s, the filter outputs go through a
+ *   decim-point backward FFT of which bin `channel` is the output item).
+ * gr_sync_block: work() returns 0 once after set_taps (.cc:138-141).  ins[s] / the device
+ * streams carry history()-1 old items in front; on the device stream s starts at
+ * d_in + s * stream_stride_items complex items.
+ * ====================================================================== */
+typedef struct grhip_pfb_decimator_ccf grhip_pfb_decimator_ccf;
+GRHIP_API int grhip_pfb_decimator_ccf_create(grhip_pfb_decimator_ccf **h, unsigned decim, const float *taps,
+                                             size_t ntaps, unsigned channel, int device);
+GRHIP_API void grhip_pfb_decimator_ccf_destroy(grhip_pfb_decimator_ccf *h);
+GRHIP_API int grhip_pfb_decimator_ccf_set_taps(grhip_pfb_decimator_ccf *h, const float *taps, size_t ntaps);
+GRHIP_API int grhip_pfb_decimator_ccf_history(const grhip_pfb_decimator_ccf *h);
+GRHIP_API int grhip_pfb_decimator_ccf_work(grhip_pfb_decimator_ccf *h, int noutput_items, const void *const *ins,
+                                           void *out);
+GRHIP_API int grhip_pfb_decimator_ccf_work_device(grhip_pfb_decimator_ccf *h, int noutput_items, const void *d_in,
+                                                  size_t stream_stride_items, void *d_out, void *stream);
+
+/* ======================================================================
  * gr_framer_sink_1  (the consumer of the correlator's flag bit)
  *   replaces gr_make_framer_sink_1(gr_msg_queue_sptr target_queue)
  *   general/gr_framer_sink_1.h:62-98, general/gr_framer_sink_1.cc:34-66 (states), 90-190 (work):

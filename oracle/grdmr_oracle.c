@@ -912,6 +912,41 @@ ORC_API int orc_pfb_general_work(orc_pfb *p, int noutput_items, const float *con
 }
 
 /* ------------------------------------------------------------------ */
+/* gr_pfb_decimator_ccf (filter/gr_pfb_decimator_ccf.cc:77-111 set_taps, */
+/* 130-180 work).  ins[s]: stream s with taps_per_filter-1 old items in   */
+/* front.  The M-point backward FFT is FFTW in the reference; here the    */
+/* double DFT rounded once (see orc_fft_vcc note): rounding unpinned.     */
+/* ------------------------------------------------------------------ */
+ORC_API unsigned orc_pfb_decimator_taps_per_filter(unsigned decim, unsigned ntaps)
+{
+    return (unsigned)ceil((double)ntaps / (double)decim);
+}
+
+ORC_API void orc_pfb_decimator_ccf_work(unsigned decim, const float *taps, unsigned ntaps, unsigned chan,
+                                        const float *const *ins, float *out, int noutput_items)
+{
+    unsigned M = decim, tpf = orc_pfb_decimator_taps_per_filter(decim, ntaps);
+    size_t tot = (size_t)M * tpf;
+    float *tmp = (float *)calloc(tot ? tot : 1, sizeof(float));
+    float *ft = (float *)calloc(tot ? tot : 1, sizeof(float));
+    memcpy(tmp, taps, sizeof(float) * ntaps);
+    for (unsigned i = 0; i < M; i++)
+        for (unsigned j = 0; j < tpf; j++) ft[i * tpf + (tpf - 1 - j)] = tmp[i + j * M];   /* :99, gr_fir reverses */
+    double *xr = (double *)malloc(sizeof(double) * M * 4);
+    double *xi = xr + M, *yr = xi + M, *yi = yr + M;
+    for (int i = 0; i < noutput_items; i++) {
+        for (int j = (int)M - 1; j >= 0; j--) {                      /* :146-160 */
+            float f[2];
+            fir_ccf_one(ft + (size_t)j * tpf, tpf, ins[M - 1 - j] + 2 * (size_t)i, f);
+            xr[j] = f[0]; xi[j] = f[1];
+        }
+        dft_double(xr, xi, yr, yi, M, 0);                            /* backward, unnormalised (:66, 167) */
+        out[2 * i] = (float)yr[chan]; out[2 * i + 1] = (float)yi[chan];   /* :170 */
+    }
+    free(xr); free(tmp); free(ft);
+}
+
+/* ------------------------------------------------------------------ */
 /* Chain drivers used by bench.py's cpu_baseline leg ("port") and by    */
 /* chain-level parity tests.  They mimic what the scheduler does for a   */
 /* whole capture: history zeros in front (runtime/gr_flat_flowgraph.cc   */

@@ -369,6 +369,18 @@ class FftFilterCcc:
         return out
 
 
+def pfb_decimator_ccf(decim, taps, chan, streams, n):
+    """gr_pfb_decimator_ccf::work: streams[s] has taps_per_filter-1 old items in front"""
+    o = _need()
+    t = np.ascontiguousarray(taps, dtype=np.float32)
+    arrs = [np.ascontiguousarray(s, dtype=np.complex64) for s in streams]
+    ptrs = (C.c_void_p * decim)(*[a.ctypes.data for a in arrs])
+    out = np.zeros(n, dtype=np.complex64)
+    o.orc_pfb_decimator_ccf_work.argtypes = [C.c_uint, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_int]
+    o.orc_pfb_decimator_ccf_work(decim, t.ctypes.data, len(t), chan, ptrs, out.ctypes.data, n)
+    return out
+
+
 class PfbChannelizer:
     """gr_pfb_channelizer_ccf restatement."""
 
