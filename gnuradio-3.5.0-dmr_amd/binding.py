@@ -9,7 +9,7 @@ __all__ = [
     "MODE_FAST", "MODE_GENERIC",
     "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
-    "clock_recovery_mm_ff", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "stream_to_streams", "streams_to_stream",
+    "clock_recovery_mm_ff", "clock_recovery_mm_cc", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "stream_to_streams", "streams_to_stream",
     "fft_vcc", "fft_filter_ccc", "pfb_channelizer_ccf", "pfb_decimator_ccf", "dmr_chain", "run_sync_block",
 ]
 
@@ -509,6 +509,58 @@ class unpack_k_bits_bb(_Block):
         L.grhip_unpack_k_bits_bb_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         n = _check(L.grhip_unpack_k_bits_bb_work(self._h, int(noutput_items), _ptr(x), _ptr(out)))
         return out[:n]
+
+
+class clock_recovery_mm_cc(_Block):
+    """digital.clock_recovery_mm_cc(omega, gain_omega, mu, gain_mu, omega_relative_limit)"""
+    _destroy = "grhip_clock_recovery_mm_cc_destroy"
+
+    def __init__(self, omega, gain_omega, mu, gain_mu, omega_relative_limit, device=0):
+        _Block.__init__(self)
+        L = lib()
+        L.grhip_clock_recovery_mm_cc_create.argtypes = [C.POINTER(C.c_void_p)] + [C.c_float] * 5 + [C.c_int]
+        _raise_like_reference(L.grhip_clock_recovery_mm_cc_create(C.byref(self._h), omega, gain_omega, mu, gain_mu,
+                                                                  omega_relative_limit, int(device)))
+
+    def forecast(self, noutput_items):
+        return _check(lib().grhip_clock_recovery_mm_cc_forecast(self._h, int(noutput_items)))
+
+    def history(self):
+        return _check(lib().grhip_clock_recovery_mm_cc_history(self._h))
+
+    def _get(self, name):
+        v = C.c_float(0)
+        f = getattr(lib(), "grhip_clock_recovery_mm_cc_" + name)
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        _check(f(self._h, C.byref(v)))
+        return np.float32(v.value)
+
+    def _set(self, name, v):
+        f = getattr(lib(), "grhip_clock_recovery_mm_cc_set_" + name)
+        f.argtypes = [C.c_void_p, C.c_float]
+        _check(f(self._h, float(v)))
+
+    def mu(self): return self._get("mu")
+    def omega(self): return self._get("omega")
+    def gain_mu(self): return self._get("gain_mu")
+    def gain_omega(self): return self._get("gain_omega")
+    def set_mu(self, v): self._set("mu", v)
+    def set_omega(self, v): self._set("omega", v)
+    def set_gain_mu(self, v): self._set("gain_mu", v)
+    def set_gain_omega(self, v): self._set("gain_omega", v)
+
+    def general_work(self, noutput_items, input_items, want_error=False):
+        """returns (out[:n], err[:n] or None, consumed)"""
+        x = np.ascontiguousarray(input_items, dtype=np.complex64)
+        out = np.zeros(max(noutput_items, 1), dtype=np.complex64)
+        err = np.zeros(max(noutput_items, 1), dtype=np.float32) if want_error else None
+        consumed = C.c_int(0)
+        L = lib()
+        L.grhip_clock_recovery_mm_cc_general_work.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                             C.c_void_p, C.POINTER(C.c_int)]
+        n = _check(L.grhip_clock_recovery_mm_cc_general_work(self._h, int(noutput_items), len(x), _ptr(x), _ptr(out),
+                                                             _ptr(err) if want_error else None, C.byref(consumed)))
+        return out[:n], (err[:n] if want_error else None), consumed.value
 
 
 class framer_sink_1(_Block):

@@ -244,6 +244,66 @@ inline grhip_binary_slicer_fb_sptr grhip_make_binary_slicer_fb(int device = 0)
     return gnuradio::get_initial_sptr(new grhip_binary_slicer_fb_blk(device));
 }
 
+// digital_clock_recovery_mm_cc (gr-digital/include/digital_clock_recovery_mm_cc.h:44-110): one complex input,
+// one complex output and the optional float error output (the shim's io signature carries one item size, so the
+// second port is described by the comment only; general_work looks at out.size() like the reference)
+class grhip_clock_recovery_mm_cc_blk;
+typedef boost::shared_ptr<grhip_clock_recovery_mm_cc_blk> grhip_clock_recovery_mm_cc_sptr;
+class grhip_clock_recovery_mm_cc_blk : public gr_block {
+    grhip_clock_recovery_mm_cc *d_h = nullptr;
+    grhip_clock_recovery_mm_cc_blk(float omega, float gain_omega, float mu, float gain_mu, float omega_relative_limit,
+                                   int device)
+        : gr_block("clock_recovery_mm_cc", gr_make_io_signature(1, 1, sizeof(gr_complex)),
+                   gr_make_io_signature(1, 2, sizeof(gr_complex)))
+    {
+        grhip_detail::check(grhip_clock_recovery_mm_cc_create(&d_h, omega, gain_omega, mu, gain_mu,
+                                                              omega_relative_limit, device));
+        set_relative_rate(1.0 / omega);                        // .cc:68
+        set_history(3);                                        // .cc:69
+        set_output_multiple(1024);
+    }
+    friend grhip_clock_recovery_mm_cc_sptr grhip_make_clock_recovery_mm_cc(float, float, float, float, float, int);
+    float get(int (*f)(grhip_clock_recovery_mm_cc *, float *)) const
+    {
+        float v = 0;
+        grhip_detail::check(f(d_h, &v));
+        return v;
+    }
+public:
+    ~grhip_clock_recovery_mm_cc_blk() { grhip_clock_recovery_mm_cc_destroy(d_h); }
+    void forecast(int noutput_items, gr_vector_int &req) override
+    {
+        int n = grhip_clock_recovery_mm_cc_forecast(d_h, noutput_items);
+        grhip_detail::check(n);
+        for (size_t i = 0; i < req.size(); i++) req[i] = n;
+    }
+    int general_work(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &in,
+                     gr_vector_void_star &out) override
+    {
+        int consumed = 0;
+        float *err = out.size() >= 2 ? (float *)out[1] : nullptr;          // .cc:124-126
+        int r = grhip_clock_recovery_mm_cc_general_work(d_h, noutput_items, ninput_items[0], in[0], out[0], err, &consumed);
+        grhip_detail::check(r);
+        consume_each(consumed);
+        return r;
+    }
+    float mu() const { return get(grhip_clock_recovery_mm_cc_mu); }
+    float omega() const { return get(grhip_clock_recovery_mm_cc_omega); }
+    float gain_mu() const { return get(grhip_clock_recovery_mm_cc_gain_mu); }
+    float gain_omega() const { return get(grhip_clock_recovery_mm_cc_gain_omega); }
+    void set_gain_mu(float v) { grhip_detail::check(grhip_clock_recovery_mm_cc_set_gain_mu(d_h, v)); }
+    void set_gain_omega(float v) { grhip_detail::check(grhip_clock_recovery_mm_cc_set_gain_omega(d_h, v)); }
+    void set_mu(float v) { grhip_detail::check(grhip_clock_recovery_mm_cc_set_mu(d_h, v)); }
+    void set_omega(float v) { grhip_detail::check(grhip_clock_recovery_mm_cc_set_omega(d_h, v)); }
+};
+inline grhip_clock_recovery_mm_cc_sptr grhip_make_clock_recovery_mm_cc(float omega, float gain_omega, float mu,
+                                                                       float gain_mu, float omega_relative_limit,
+                                                                       int device = 0)
+{
+    return gnuradio::get_initial_sptr(
+        new grhip_clock_recovery_mm_cc_blk(omega, gain_omega, mu, gain_mu, omega_relative_limit, device));
+}
+
 // pager_slicer_fb (gr-pager/lib/pager_slicer_fb.h:30-58), gr_unpack_k_bits_bb (general/gr_unpack_k_bits_bb.h)
 class grhip_pager_slicer_fb_blk;
 typedef boost::shared_ptr<grhip_pager_slicer_fb_blk> grhip_pager_slicer_fb_sptr;

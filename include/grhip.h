@@ -260,6 +260,39 @@ GRHIP_API int grhip_unpack_k_bits_bb_work_device(grhip_unpack_k_bits_bb *h, int 
                                                  const unsigned char *d_in, unsigned char *d_out, void *stream);
 
 /* ======================================================================
+ * digital_clock_recovery_mm_cc  (the complex sibling of the M&M timing loop)
+ *   replaces digital_make_clock_recovery_mm_cc(float omega, float gain_omega, float mu,
+ *                                              float gain_mu, float omega_relative_limit)
+ *   gr-digital/include/digital_clock_recovery_mm_cc.h:44-110,
+ *   gr-digital/lib/digital_clock_recovery_mm_cc.cc:37-215 (FUDGE = 16, history 3)
+ * gr_block: general_work(noutput_items, ninput_items, in, out, err, &consumed) returns the items
+ * produced and stores what consume_each() would get; `err` is the optional second output (the
+ * clipped timing error, .cc:137-168) and may be NULL -- as in the reference its presence selects
+ * the clip limit (4.0 with, 1.0 without).  GRHIP_ERANGE for omega <= 0 or negative gains (.cc:62-65).
+ * Getters store into *v and return a status.
+ * ====================================================================== */
+typedef struct grhip_clock_recovery_mm_cc grhip_clock_recovery_mm_cc;
+GRHIP_API int grhip_clock_recovery_mm_cc_create(grhip_clock_recovery_mm_cc **h, float omega, float gain_omega,
+                                                float mu, float gain_mu, float omega_relative_limit, int device);
+GRHIP_API void grhip_clock_recovery_mm_cc_destroy(grhip_clock_recovery_mm_cc *h);
+GRHIP_API int grhip_clock_recovery_mm_cc_forecast(grhip_clock_recovery_mm_cc *h, int noutput_items);
+GRHIP_API int grhip_clock_recovery_mm_cc_history(const grhip_clock_recovery_mm_cc *h);
+GRHIP_API int grhip_clock_recovery_mm_cc_general_work(grhip_clock_recovery_mm_cc *h, int noutput_items,
+                                                      int ninput_items, const void *in, void *out, float *err,
+                                                      int *consumed);
+GRHIP_API int grhip_clock_recovery_mm_cc_general_work_device(grhip_clock_recovery_mm_cc *h, int noutput_items,
+                                                             int ninput_items, const void *d_in, void *d_out,
+                                                             float *d_err, int *consumed, void *stream);
+GRHIP_API int grhip_clock_recovery_mm_cc_mu(grhip_clock_recovery_mm_cc *h, float *v);
+GRHIP_API int grhip_clock_recovery_mm_cc_omega(grhip_clock_recovery_mm_cc *h, float *v);
+GRHIP_API int grhip_clock_recovery_mm_cc_gain_mu(grhip_clock_recovery_mm_cc *h, float *v);
+GRHIP_API int grhip_clock_recovery_mm_cc_gain_omega(grhip_clock_recovery_mm_cc *h, float *v);
+GRHIP_API int grhip_clock_recovery_mm_cc_set_mu(grhip_clock_recovery_mm_cc *h, float v);
+GRHIP_API int grhip_clock_recovery_mm_cc_set_omega(grhip_clock_recovery_mm_cc *h, float v);
+GRHIP_API int grhip_clock_recovery_mm_cc_set_gain_mu(grhip_clock_recovery_mm_cc *h, float v);
+GRHIP_API int grhip_clock_recovery_mm_cc_set_gain_omega(grhip_clock_recovery_mm_cc *h, float v);
+
+/* ======================================================================
  * gr_pfb_decimator_ccf  (polyphase decimator, one output channel)
  *   replaces gr_make_pfb_decimator_ccf(unsigned decim, const std::vector<float> &taps,
  *                                      unsigned channel)

@@ -518,6 +518,76 @@ ORC_API void orc_unpack_k_bits_bb(unsigned k, const unsigned char *in, unsigned 
 }
 
 /* ------------------------------------------------------------------ */
+/* digital_clock_recovery_mm_cc (gr-digital/lib/digital_clock_recovery_mm_cc.cc:49-215, */
+/* include/digital_clock_recovery_mm_cc.h:67-110) with gri_mmse_fir_interpolator_cc     */
+/* (filter/gri_mmse_fir_interpolator_cc.cc:33-80: the same tap table through gr_fir_ccf).*/
+/* ------------------------------------------------------------------ */
+typedef struct {
+    float mu, omega, min_omega, omega_mid, max_omega;
+    float gain_omega, gain_mu, omega_relative_limit;
+    float p_2T[2], p_1T[2], p_0T[2], c_2T[2], c_1T[2], c_0T[2];
+} orc_mmcc;
+
+ORC_API size_t orc_mmcc_size(void) { return sizeof(orc_mmcc); }
+
+ORC_API int orc_mmcc_init(orc_mmcc *s, float omega, float gain_omega, float mu, float gain_mu, float rel)
+{
+    if (omega <= 0.0) return -1;                                   /* .cc:62-63 */
+    if (gain_mu < 0 || gain_omega < 0) return -1;                  /* .cc:64-65 */
+    memset(s, 0, sizeof(*s));
+    s->mu = mu; s->gain_omega = gain_omega; s->gain_mu = gain_mu; s->omega_relative_limit = rel;
+    s->omega = omega;                                              /* set_omega, .h:76-81 */
+    s->min_omega = omega * (1.0 - rel);
+    s->max_omega = omega * (1.0 + rel);
+    s->omega_mid = 0.5 * (s->min_omega + s->max_omega);
+    return 0;
+}
+
+ORC_API int orc_mmcc_forecast(const orc_mmcc *s, int noutput_items)
+{
+    return (int)ceil((noutput_items * s->omega) + MMSE_NTAPS) + 16;   /* .cc:82-83, FUDGE = 16 */
+}
+
+ORC_API float orc_mmcc_mu(const orc_mmcc *s) { return s->mu; }
+ORC_API float orc_mmcc_omega(const orc_mmcc *s) { return s->omega; }
+
+/* general_work (.cc:117-215): foptr may be NULL (second loop: clip 1.0 instead of 4.0) */
+ORC_API int orc_mmcc_general_work(orc_mmcc *s, int noutput_items, int ninput_items, const float *in, float *out,
+                                  float *foptr, int *consumed)
+{
+    if (!mmse_ready) mmse_init();
+    int ii = 0, oo = 0;
+    int ni = ninput_items - MMSE_NTAPS - 16;
+    const float lim = foptr ? 4.0f : 1.0f;
+    while (oo < noutput_items && ii < ni) {
+        s->p_2T[0] = s->p_1T[0]; s->p_2T[1] = s->p_1T[1];
+        s->p_1T[0] = s->p_0T[0]; s->p_1T[1] = s->p_0T[1];
+        int imu = (int)rint(s->mu * MMSE_NSTEPS);
+        fir_ccf_one(mmse_rev[imu], MMSE_NTAPS, in + 2 * (size_t)ii, s->p_0T);
+        s->c_2T[0] = s->c_1T[0]; s->c_2T[1] = s->c_1T[1];
+        s->c_1T[0] = s->c_0T[0]; s->c_1T[1] = s->c_0T[1];
+        s->c_0T[0] = s->p_0T[0] > 0 ? 1.0f : 0.0f;                 /* slicer_0deg, .cc:86-96 */
+        s->c_0T[1] = s->p_0T[1] > 0 ? 1.0f : 0.0f;
+        float xr, xi, yr, yi;
+        cmul(s->c_0T[0] - s->c_2T[0], s->c_0T[1] - s->c_2T[1], s->p_1T[0], -s->p_1T[1], &xr, &xi);   /* .cc:147 */
+        cmul(s->p_0T[0] - s->p_2T[0], s->p_0T[1] - s->p_2T[1], s->c_1T[0], -s->c_1T[1], &yr, &yi);   /* .cc:148 */
+        float mm_val = yr - xr;                                    /* u = y - x; u.real() */
+        out[2 * oo] = s->p_0T[0]; out[2 * oo + 1] = s->p_0T[1];
+        oo++;
+        mm_val = orc_branchless_clip(mm_val, lim);
+        s->omega = s->omega + s->gain_omega * mm_val;
+        s->omega = s->omega_mid + orc_branchless_clip(s->omega - s->omega_mid, s->omega_relative_limit);
+        s->mu = s->mu + s->omega + s->gain_mu * mm_val;
+        ii += (int)floor(s->mu);
+        s->mu -= floor(s->mu);
+        if (foptr) foptr[oo - 1] = mm_val;
+        if (ii < 0) ii = 0;
+    }
+    if (consumed) *consumed = ii > 0 ? ii : 0;
+    return oo;
+}
+
+/* ------------------------------------------------------------------ */
 /* gr_framer_sink_1 (general/gr_framer_sink_1.cc:34-66 state entries,     */
 /* 90-190 work; general/gr_framer_sink_1.h:62-98 state, header_ok,       */
 /* header_payload).  Messages are appended to caller arrays instead of    */

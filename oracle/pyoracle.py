@@ -221,6 +221,48 @@ class ClockRecoveryMM:
                     omega_mid=np.float32(self.s.omega_mid))
 
 
+class ClockRecoveryMMcc:
+    """digital_clock_recovery_mm_cc restatement."""
+
+    def __init__(self, omega, gain_omega, mu, gain_mu, omega_relative_limit):
+        o = _need()
+        o.orc_mmcc_size.restype = C.c_size_t
+        self.s = C.create_string_buffer(o.orc_mmcc_size())
+        o.orc_mmcc_init.argtypes = [C.c_void_p] + [C.c_float] * 5
+        if o.orc_mmcc_init(self.s, omega, gain_omega, mu, gain_mu, omega_relative_limit):
+            raise IndexError("out_of_range")
+
+    def forecast(self, nout):
+        o = _need()
+        o.orc_mmcc_forecast.argtypes = [C.c_void_p, C.c_int]
+        return o.orc_mmcc_forecast(self.s, nout)
+
+    def general_work(self, nout, x, want_error=False):
+        """returns (out[:n], err[:n] or None, consumed)"""
+        o = _need()
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.zeros(max(nout, 1), dtype=np.complex64)
+        err = np.zeros(max(nout, 1), dtype=np.float32) if want_error else None
+        consumed = C.c_int(0)
+        o.orc_mmcc_general_work.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_int)]
+        n = o.orc_mmcc_general_work(self.s, nout, len(x), x.ctypes.data, out.ctypes.data,
+                                    err.ctypes.data if want_error else None, C.byref(consumed))
+        return out[:n].copy(), (err[:n].copy() if want_error else None), consumed.value
+
+    def mu(self):
+        o = _need()
+        o.orc_mmcc_mu.restype = C.c_float
+        o.orc_mmcc_mu.argtypes = [C.c_void_p]
+        return np.float32(o.orc_mmcc_mu(self.s))
+
+    def omega(self):
+        o = _need()
+        o.orc_mmcc_omega.restype = C.c_float
+        o.orc_mmcc_omega.argtypes = [C.c_void_p]
+        return np.float32(o.orc_mmcc_omega(self.s))
+
+
 class PagerSlicer:
     """pager_slicer_fb: state (d_avg) carried across work() calls"""
 
