@@ -138,10 +138,23 @@ int XlatingCore::build(int device)
     }
     // same crossover as gr_fir_filter (see there); single-stream calls only, batched launches stay tiled
     prefer_ols = use_ols && (!use_tiled || ntaps / decim > 120);
-    use_hidec = !use_tiled && hidec_wanted(decim, ntaps, true, use_ols);
+    // real prototype: pre-mix form, half the FMAs for one more multiply per staged sample -- pays from about 16
+    // taps per polyphase component (tools/bench_decim.py)
+    hidec_premix = real_proto && ntaps > 0 && ntaps / decim >= 16;
+    use_hidec = !use_tiled && hidec_wanted(decim, ntaps, !hidec_premix, use_ols);
     if (use_hidec) {
         std::vector<float> hp2;
-        hidec_pad_taps((const float *)ctaps.data(), ntaps, 2, decim, hp2);
+        if (hidec_premix) {
+            std::vector<float> pr(ntaps), et, vt;
+            for (int i = 0; i < ntaps; ++i) pr[i] = proto[i].real();
+            hidec_pad_taps(pr.data(), ntaps, 1, decim, hp2);
+            hidec_premix_tables(omega, decim, et, vt);
+            rc = upload(d_hidec_etab, et.data(), et.size() * sizeof(float));
+            if (!rc) rc = upload(d_hidec_vtab, vt.data(), vt.size() * sizeof(float));
+            if (rc) return rc;
+        } else {
+            hidec_pad_taps((const float *)ctaps.data(), ntaps, 2, decim, hp2);
+        }
         rc = upload(d_hidec_taps, hp2.data(), hp2.size() * sizeof(float));
         if (rc) return rc;
     }
@@ -222,6 +235,7 @@ void XlatingCore::release()
 {
     d_taps_generic.release(); d_hp.release(); d_wtab.release(); d_stab.release(); d_vtab.release(); d_rot.release();
     scratch_y.release(); sched.release(); d_ols_tw.release(); d_ols_H.release(); d_hidec_taps.release();
+    d_hidec_etab.release(); d_hidec_vtab.release();
 }
 
 // run the FIR + rotator (+ demod) for n_out outputs on device pointers.
@@ -290,8 +304,10 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
             GRHIP_HIP(hipMemcpyAsync(scratch_y.p, y_prev, sizeof(float2), hipMemcpyDeviceToDevice, st));
         }
         if (use_hidec) {
-            rc = launch_fir_hidec(true, d_hidec_taps.as<float>(), ntaps, decim, d_in, (n_out - 1) * decim + ntaps, y, n_out,
-                                  gtab, st);                 // rotator multiply inside
+            rc = launch_fir_hidec(!hidec_premix, d_hidec_taps.as<float>(), ntaps, decim, d_in, (n_out - 1) * decim + ntaps, y,
+                                  n_out, gtab, st,           // rotator multiply inside
+                                  hidec_premix ? d_hidec_etab.as<float2>() : nullptr,
+                                  hidec_premix ? d_hidec_vtab.as<float2>() : nullptr);
         } else {
             rc = launch_fftfilt4096(d_in + (ntaps - 1), (n_out - 1) * decim + 1, d_in, ntaps, d_ols_tw.as<float2>(),
                                     d_ols_H.as<float2>(), y, n_out, decim, ols_L, ols_fold, st);

@@ -67,8 +67,12 @@ int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiled
 bool hidec_supported(int decim, int ntaps);
 int hidec_outputs_per_tile(int decim, int ntaps);
 void hidec_pad_taps(const float *taps_corr, int ntaps, int tw, int decim, std::vector<float> &out);
-int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in,
-                     float2 *y, long long n_out, const float2 *gtab, hipStream_t st);
+void hidec_premix_tables(double omega, int decim, std::vector<float> &etab, std::vector<float> &vtab);
+// etab / vtab (both or neither): pre-mix form for freq_xlating with a real prototype -- taps_padded are then the REAL
+// prototype taps and the result is the band-pass sum (times gtab)
+int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in, float2 *y,
+                     long long n_out, const float2 *gtab, hipStream_t st, const float2 *etab = nullptr,
+                     const float2 *vtab = nullptr);
 
 // in-place rotator multiply with a phase table (gr_rotator.h:43)
 int launch_rotate(float2 *y, const float2 *gtab, long long n, hipStream_t st);

@@ -235,10 +235,14 @@ bool hidec_supported(int D, int ntaps)
     return D >= 3 && D <= 256 && ntaps >= 1 && ntaps <= 2048 && hidec_outputs_per_tile(D, ntaps) >= 128;
 }
 
-template <bool CTAPS, int V1>
+// PREMIX (freq_xlating with a real prototype): y_bp[n0+m] = e^{-jw m D} sum_k proto[k] (x[u0+u] e^{jwu}), u = mD + k
+// relative to the tile: the samples are mixed with etab[u] = e^{jwu} while they are staged, the taps are the
+// real prototype (half the FMAs), and the lane's outputs are turned back with vtab[m] = e^{-jw m D}.
+template <bool CTAPS, int V1, bool PREMIX>
 __global__ void __launch_bounds__(256, 3)
 fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__restrict__ taps_g, int ntaps, int D,
-                 int Tn, long long n_out, float2 *__restrict__ y, const float2 *__restrict__ gtab)
+                 int Tn, long long n_out, float2 *__restrict__ y, const float2 *__restrict__ gtab,
+                 const float2 *__restrict__ etab, const float2 *__restrict__ vtab)
 {
     __shared__ float2 xs[HIDEC_LDS_SAMPLES + 128];             // 2P sub-arrays of odd stride: at most S + 3*2P slots
     typedef const float __attribute__((address_space(4))) *cfp;
@@ -260,7 +264,11 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int u = ub + 256 * j;
-            if (u < ns) xs[(u & PM) * SUB + (u >> V1)] = u0 + u < n_in ? v[j] : make_float2(0.f, 0.f);
+            if (u < ns) {
+                float2 w = u0 + u < n_in ? v[j] : make_float2(0.f, 0.f);
+                if (PREMIX) w = cmul_ref(w, etab[u]);
+                xs[(u & PM) * SUB + (u >> V1)] = w;
+            }
         }
     }
     __syncthreads();
@@ -306,6 +314,10 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
     }
     (void)mac;
     const long long n = n0 + 2 * t;
+    if (PREMIX) {
+        a0 = cmul_ref(a0, vtab[2 * t]);
+        a1 = cmul_ref(a1, vtab[2 * t + 1]);
+    }
     if (gtab) {
         if (n < n_out) a0 = cmul_ref(a0, gtab[n]);
         if (n + 1 < n_out) a1 = cmul_ref(a1, gtab[n + 1]);
@@ -319,26 +331,43 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
 }
 
 int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in,
-                     float2 *y, long long n_out, const float2 *gtab, hipStream_t st)
+                     float2 *y, long long n_out, const float2 *gtab, hipStream_t st, const float2 *etab, const float2 *vtab)
 {
     if (n_out <= 0) return GRHIP_OK;
     if (!hidec_supported(decim, ntaps) || n_in < 1) return fail(GRHIP_EINVAL, "high-decimation FIR: unsupported shape");
+    const bool premix = etab && vtab;
+    if (premix && ctaps) return fail(GRHIP_EINVAL, "high-decimation FIR: pre-mix form takes real taps");
     const int Tn = hidec_outputs_per_tile(decim, ntaps);
     const unsigned blocks = (unsigned)((n_out + Tn - 1) / Tn);
     const int v1 = hidec_sub_log(decim);
-#define GRHIP_HIDEC(C, V)                                                                                            \
-    hipLaunchKernelGGL((fir_hidec_kernel<C, V>), dim3(blocks), dim3(256), 0, st, x, n_in, taps_padded, ntaps, decim, Tn, \
-                       n_out, y, gtab)
-    if (ctaps) {
-        switch (v1) { case 1: GRHIP_HIDEC(true, 1); break; case 2: GRHIP_HIDEC(true, 2); break; case 3: GRHIP_HIDEC(true, 3); break;
-                      case 4: GRHIP_HIDEC(true, 4); break; default: GRHIP_HIDEC(true, 5); break; }
-    } else {
-        switch (v1) { case 1: GRHIP_HIDEC(false, 1); break; case 2: GRHIP_HIDEC(false, 2); break; case 3: GRHIP_HIDEC(false, 3); break;
-                      case 4: GRHIP_HIDEC(false, 4); break; default: GRHIP_HIDEC(false, 5); break; }
-    }
+#define GRHIP_HIDEC(C, V, P)                                                                                            \
+    hipLaunchKernelGGL((fir_hidec_kernel<C, V, P>), dim3(blocks), dim3(256), 0, st, x, n_in, taps_padded, ntaps, decim, \
+                       Tn, n_out, y, gtab, etab, vtab)
+#define GRHIP_HIDEC_V(C, P)                                                                                  \
+    switch (v1) { case 1: GRHIP_HIDEC(C, 1, P); break; case 2: GRHIP_HIDEC(C, 2, P); break;                  \
+                  case 3: GRHIP_HIDEC(C, 3, P); break; case 4: GRHIP_HIDEC(C, 4, P); break;                  \
+                  default: GRHIP_HIDEC(C, 5, P); break; }
+    if (premix) { GRHIP_HIDEC_V(false, true) }
+    else if (ctaps) { GRHIP_HIDEC_V(true, false) }
+    else { GRHIP_HIDEC_V(false, false) }
+#undef GRHIP_HIDEC_V
 #undef GRHIP_HIDEC
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
+}
+
+// phasor tables of the pre-mix form (double precision angles): etab[u] = e^{jwu}, vtab[m] = e^{-jw m decim}
+void hidec_premix_tables(double omega, int decim, std::vector<float> &etab, std::vector<float> &vtab)
+{
+    etab.resize(2 * (size_t)(HIDEC_LDS_SAMPLES + 128));
+    for (int u = 0; u < HIDEC_LDS_SAMPLES + 128; ++u) {
+        etab[2 * u] = (float)cos(omega * u); etab[2 * u + 1] = (float)sin(omega * u);
+    }
+    vtab.resize(2 * 512);
+    for (int m = 0; m < 512; ++m) {
+        const double a = -omega * (double)m * (double)decim;
+        vtab[2 * m] = (float)cos(a); vtab[2 * m + 1] = (float)sin(a);
+    }
 }
 
 // taps for launch_fir_hidec: correlation order, D zero taps in front and behind + one group of slack

@@ -36,7 +36,8 @@ struct XlatingCore {
     // overlap-save engine (fft_kernels.hip) + rotator table multiply
     bool use_ols = false, prefer_ols = false, use_hidec = false;
     int ols_L = 0, ols_fold = 0;
-    DevBuf d_ols_tw, d_ols_H, d_hidec_taps;
+    DevBuf d_ols_tw, d_ols_H, d_hidec_taps, d_hidec_etab, d_hidec_vtab;
+    bool hidec_premix = false;
     DevBuf scratch_y;
     SchedBuf sched;                             // tile queue of the tiled kernel (one launch at a time per handle)
 

@@ -152,14 +152,18 @@ def test_xlating_generic_bit_exact_and_rotator_carry(gpu, po, wl):
     assert bits_equal(got, ref)
 
 
-@pytest.mark.parametrize("decim,ntaps", [(10, 256), (5, 1200), (25, 400), (8, 300), (16, 512)])
-def test_xlating_fast_other_decimations(gpu, po, wl, decim, ntaps):
-    """decimations the tiled kernel does not take (and prototypes beyond its 1024 taps): FAST mode goes
-    through the overlap-save engine + rotator table (+ stand-alone demodulator), chunked calls included"""
+@pytest.mark.parametrize("complex_proto", [False, True])
+@pytest.mark.parametrize("decim,ntaps", [(10, 256), (5, 1200), (25, 400), (8, 300), (16, 512), (20, 400), (7, 64), (3, 40)])
+def test_xlating_fast_other_decimations(gpu, po, wl, decim, ntaps, complex_proto):
+    """decimations the tiled kernel does not take (and prototypes beyond its 1024 taps): FAST mode goes through the
+    high-decimation direct kernel (pre-mix form for a real prototype, complex taps otherwise) or the overlap-save
+    engine, + rotator table (+ stand-alone demodulator), chunked calls included"""
     c = wl.CFG2
     n = 300_000
     x = wl.fsk4_capture(n, stream_id=31)
     proto = wl.lowpass_taps(ntaps, 0.02, 1.0).astype(np.complex64)
+    if complex_proto:
+        proto = (proto * np.exp(1j * 0.013 * np.arange(ntaps))).astype(np.complex64)
     nout = n // decim
     xin = wl.with_history(x[: nout * decim], ntaps - 1)
     ref = po.Xlating(decim, proto, c["center_freq"], c["fs"]).work(xin, nout)
