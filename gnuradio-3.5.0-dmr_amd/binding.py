@@ -9,7 +9,7 @@ __all__ = [
     "MODE_FAST", "MODE_GENERIC",
     "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
-    "clock_recovery_mm_ff", "clock_recovery_mm_cc", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "stream_to_streams", "streams_to_stream",
+    "clock_recovery_mm_ff", "clock_recovery_mm_cc", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "stream_to_streams", "streams_to_stream", "vector_to_streams", "stream_to_vector", "head",
     "fft_vcc", "fft_filter_ccc", "pfb_channelizer_ccf", "pfb_decimator_ccf", "dmr_chain", "run_sync_block",
 ]
 
@@ -563,6 +563,52 @@ class clock_recovery_mm_cc(_Block):
         return out[:n], (err[:n] if want_error else None), consumed.value
 
 
+class _copy_adapter(_Block):
+    _destroy = "grhip_copy_adapter_destroy"
+
+    def work(self, noutput_items, input_items):
+        x = np.ascontiguousarray(input_items)
+        out = np.zeros(max(noutput_items, 1) * self.out_bytes, dtype=np.uint8)
+        L = lib()
+        L.grhip_copy_adapter_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        n = L.grhip_copy_adapter_work(self._h, int(noutput_items), _ptr(x), _ptr(out))
+        if n == -1:
+            return None                                    # WORK_DONE
+        _check(n)
+        return out[:n * self.out_bytes].view(x.dtype)
+
+    def work_device(self, noutput_items, d_in, d_out, stream=None):
+        L = lib()
+        L.grhip_copy_adapter_work_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        n = L.grhip_copy_adapter_work_device(self._h, int(noutput_items), _devptr(d_in), _devptr(d_out), _stream(stream))
+        return n if n == -1 else _check(n)
+
+
+class stream_to_vector(_copy_adapter):
+    """gr.stream_to_vector(item_size, nitems_per_block)"""
+
+    def __init__(self, item_size, nitems_per_block, device=0):
+        _Block.__init__(self)
+        L = lib()
+        L.grhip_stream_to_vector_create.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, C.c_int]
+        _check(L.grhip_stream_to_vector_create(C.byref(self._h), int(item_size), int(nitems_per_block), int(device)))
+        self.out_bytes = int(item_size) * int(nitems_per_block)
+
+
+class head(_copy_adapter):
+    """gr.head(sizeof_stream_item, nitems): work() returns None (WORK_DONE, -1) once nitems have passed"""
+
+    def __init__(self, sizeof_stream_item, nitems, device=0):
+        _Block.__init__(self)
+        L = lib()
+        L.grhip_head_create.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_ulonglong, C.c_int]
+        _check(L.grhip_head_create(C.byref(self._h), int(sizeof_stream_item), int(nitems), int(device)))
+        self.out_bytes = int(sizeof_stream_item)
+
+    def reset(self):
+        _check(lib().grhip_head_reset(self._h))
+
+
 class framer_sink_1(_Block):
     """gr.framer_sink_1(msgq): header + payload extraction after the correlator's flag bit.
     The reference inserts gr.message objects into `msgq`; here work() / work_device() collect them
@@ -634,6 +680,11 @@ class stream_to_streams(_stream_adapter):
         outs = [np.zeros(noutput_items, dtype=x.dtype) for _ in range(self.nstreams)]
         self._work(noutput_items, x, outs)
         return outs
+
+
+class vector_to_streams(stream_to_streams):
+    """gr.vector_to_streams(item_size, nstreams): item j of every input vector -> stream j (same data movement as
+    stream_to_streams, general/gr_vector_to_streams.cc:45-70)"""
 
 
 class streams_to_stream(_stream_adapter):

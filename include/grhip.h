@@ -260,6 +260,31 @@ GRHIP_API int grhip_unpack_k_bits_bb_work_device(grhip_unpack_k_bits_bb *h, int 
                                                  const unsigned char *d_in, unsigned char *d_out, void *stream);
 
 /* ======================================================================
+ * gr_stream_to_vector, gr_vector_to_streams, gr_head  (the remaining harness adapters)
+ *   gr_make_stream_to_vector(size_t item_size, size_t nitems_per_block)
+ *       general/gr_stream_to_vector.cc:31-60: gr_sync_decimator, work = one memcpy: grouping items into
+ *       vectors moves no data;
+ *   gr_make_head(size_t sizeof_stream_item, unsigned long long nitems)
+ *       general/gr_head.cc:31-62: copies until nitems have passed, then work() returns -1 (WORK_DONE);
+ *   gr_make_vector_to_streams(size_t item_size, size_t nstreams)
+ *       general/gr_vector_to_streams.cc:31-70: item j of every input vector goes to stream j -- the data
+ *       movement of gr_stream_to_streams: create it with grhip_stream_adapter_create(split = 1, ...).
+ * work(): host pointers (a host memcpy, as the reference); work_device(): device pointers, the copy is
+ * queued on `stream` (0 = the handle's own).  noutput_items counts OUTPUT items (vectors for
+ * stream_to_vector).
+ * ====================================================================== */
+typedef struct grhip_copy_adapter grhip_copy_adapter;
+GRHIP_API int grhip_stream_to_vector_create(grhip_copy_adapter **h, size_t item_size, size_t nitems_per_block,
+                                            int device);
+GRHIP_API int grhip_head_create(grhip_copy_adapter **h, size_t sizeof_stream_item, unsigned long long nitems,
+                                int device);
+GRHIP_API int grhip_head_reset(grhip_copy_adapter *h);
+GRHIP_API void grhip_copy_adapter_destroy(grhip_copy_adapter *h);
+GRHIP_API int grhip_copy_adapter_work(grhip_copy_adapter *h, int noutput_items, const void *in, void *out);
+GRHIP_API int grhip_copy_adapter_work_device(grhip_copy_adapter *h, int noutput_items, const void *d_in, void *d_out,
+                                             void *stream);
+
+/* ======================================================================
  * digital_clock_recovery_mm_cc  (the complex sibling of the M&M timing loop)
  *   replaces digital_make_clock_recovery_mm_cc(float omega, float gain_omega, float mu,
  *                                              float gain_mu, float omega_relative_limit)

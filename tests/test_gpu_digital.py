@@ -216,3 +216,31 @@ def test_stream_to_streams_and_back(gpu, dtype, nstreams):
         assert np.array_equal(outs[j].view(np.uint8).reshape(n, -1), want[:, j, :])
     back = gpu.streams_to_stream(np.dtype(dtype).itemsize, nstreams).work(n * nstreams, outs)
     assert np.array_equal(back.view(np.uint8), x.view(np.uint8))
+
+
+def test_remaining_harness_adapters(gpu):
+    """gr_stream_to_vector (a copy), gr_vector_to_streams (= stream_to_streams), gr_head (WORK_DONE)"""
+    import torch
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal(4096 * 3) + 1j * rng.standard_normal(4096 * 3)).astype(np.complex64)
+    s2v = gpu.stream_to_vector(8, 4096)
+    assert np.array_equal(s2v.work(3, x), x)                                   # general/gr_stream_to_vector.cc:46-60
+    v2s = gpu.vector_to_streams(8, 4)
+    outs = v2s.work(len(x) // 4, x)
+    assert all(np.array_equal(outs[j], x[j::4]) for j in range(4))               # general/gr_vector_to_streams.cc:58-65
+    h = gpu.head(8, 5000)
+    a = h.work(4096, x[:4096])
+    b = h.work(4096, x[4096:8192])
+    assert len(a) == 4096 and len(b) == 5000 - 4096 and np.array_equal(b, x[4096:5000])
+    assert h.work(4096, x[:4096]) is None                                        # general/gr_head.cc:49-50
+    h.reset()
+    assert len(h.work(10, x[:10])) == 10
+    # device pointers: the copy is queued on the caller's stream
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    d = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev)
+    o = torch.zeros_like(d)
+    h2 = gpu.head(8, 1000)
+    assert h2.work_device(4096, d, o, st) == 1000 and h2.work_device(4096, d, o, st) == -1
+    st.synchronize()
+    assert torch.equal(o[:1000], d[:1000]) and float(o[1000:].abs().sum()) == 0.0
