@@ -13,6 +13,7 @@
 //   3. framer_payload_kernel  the payload bytes of all jobs, one lane per byte, from the packed data words.
 // Messages (whitener offset = gr_message arg1, payload) collect in a device pool until the host fetches them.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -206,6 +207,226 @@ framer_walk_kernel(const unsigned *__restrict__ F, const unsigned *__restrict__ 
     }
 }
 
+// ---- segment-parallel walk (long calls) --------------------------------------------------------------
+// The walk is serial only through "where does the search resume".  Every segment of `seg` items is walked by its
+// own wavefront as if the search state held at its first item (framer_segwalk_kernel: one record per packet,
+// with running message / payload-byte counts).  A single wavefront then goes through the segments in order
+// (framer_fixup_kernel): when the true resume position lies at or before a segment's start, or in one of the
+// gaps between the packets the speculative walk found, both walks see the same next flag and everything from
+// there on is taken over wholesale; only when it falls inside a speculative packet does the fix-up walk packets
+// itself until the two coincide.  framer_emit_kernel finally turns the accepted records into message records
+// and payload jobs at the indices the fix-up assigned.
+struct FrRec { unsigned p, h, cmsg, cbytes; };   // flag position, header bits, messages / payload bytes before it in the segment
+struct FrSeg { unsigned cnt, totm, totb, exit, acc, mbase, bbase, pad; };
+
+__device__ inline bool fr_good(unsigned h) { return ((h >> 16) ^ (h & 0xffffu)) == 0; }
+__device__ inline unsigned fr_len(unsigned h) { return (h >> 16) & 0x0fffu; }
+
+// next flagged item in [pos, lim), or lim; F zero padded behind n
+__device__ inline unsigned fr_next_flag(const unsigned *__restrict__ F, unsigned nwords, unsigned pos, unsigned lim, unsigned lane)
+{
+    while (pos < lim) {
+        const unsigned w0 = pos >> 5, wi = w0 + lane;
+        unsigned f = wi < nwords ? F[wi] : 0u;
+        if (lane == 0) f &= 0xffffffffu >> (pos & 31u);
+        const unsigned long long bal = __ballot(f != 0u);
+        if (bal == 0ull) { pos = (w0 + 64u) << 5; continue; }
+        const int L = __ffsll((long long)bal) - 1;
+        const unsigned word = __builtin_amdgcn_readlane(f, L);
+        const unsigned p = ((w0 + (unsigned)L) << 5) + (unsigned)__clz((int)word);
+        return p < lim ? p : lim;
+    }
+    return lim;
+}
+
+// k (1..32) data bits starting at item s (wave-uniform address: scalar loads)
+__device__ inline unsigned fr_bits(const unsigned *__restrict__ D, unsigned s, int k)
+{
+    const unsigned i = s >> 5;
+    const unsigned long long w = ((unsigned long long)D[i] << 32) | D[i + 1];
+    return (unsigned)((w << (s & 31u)) >> (64 - k));
+}
+
+__global__ void __launch_bounds__(64)
+framer_segwalk_kernel(const unsigned *__restrict__ F, const unsigned *__restrict__ D, unsigned n, unsigned seg,
+                      unsigned reccap, FrRec *__restrict__ recs, FrSeg *__restrict__ segs)
+{
+    const unsigned lane = threadIdx.x, k = blockIdx.x;
+    const unsigned nwords = (n + 31u) >> 5;
+    const unsigned s0 = k * seg, s1 = min(s0 + seg, n);
+    FrRec *r = recs + (size_t)k * reccap;
+    unsigned pos = s0, cnt = 0, cm = 0, cb = 0;
+    while (pos < s1) {
+        const unsigned p = fr_next_flag(F, nwords, pos, s1, lane);
+        if (p >= s1) { pos = s1; break; }
+        if (p + 32u > n) {                                  // header cut off by the end of the call
+            if (lane == 0) r[cnt] = FrRec{p, fr_bits(D, p, (int)(n - p)), cm, cb};
+            ++cnt;
+            pos = p + 32u;
+            break;
+        }
+        const unsigned h = fr_bits(D, p, 32);
+        if (lane == 0) r[cnt] = FrRec{p, h, cm, cb};
+        ++cnt;
+        pos = p + 32u;
+        if (fr_good(h)) { ++cm; cb += fr_len(h); pos += 8u * fr_len(h); }
+    }
+    if (lane == 0) segs[k] = FrSeg{cnt, cm, cb, pos, 0u, 0u, 0u, 0u};
+}
+
+// where the search resumes after the packet of record (p, h); a header cut off by the end of the call ends behind it
+__device__ inline unsigned fr_end(unsigned p, unsigned h, unsigned n)
+{
+    if (p + 32u > n || !fr_good(h)) return p + 32u;
+    return p + 32u + 8u * fr_len(h);
+}
+
+__global__ void __launch_bounds__(64)
+framer_fixup_kernel(const unsigned *__restrict__ F, const unsigned *__restrict__ D, unsigned n, unsigned seg, unsigned nseg,
+                    unsigned reccap, const FrRec *__restrict__ recs, FrSeg *__restrict__ segs, FramerState *S,
+                    FramerMsg *msgs, FramerJob *jobs)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned nwords = (n + 31u) >> 5;
+    int mode = uni(S->mode), hdr_cnt = uni(S->hdr_cnt), pktlen = uni(S->pktlen), woff = uni(S->woff), bits_done = uni(S->bits_done);
+    unsigned header = uni(S->header), M = uni(S->msg_count), B = uni(S->pool_used), open_off = uni(S->open_off);
+    unsigned pos = 0;
+    if (lane == 0) jobs[0] = FramerJob{0u, 0u, 0u, 0u};      // slot of a packet continued from the previous call
+
+    // ---- the packet the previous call left open (same steps as framer_walk_kernel) ----
+    bool finished = false;                                   // the call ends inside that packet
+    if (mode == FR_HAVE_SYNC) {
+        const unsigned need = 32u - (unsigned)hdr_cnt;
+        const int take = (int)(n < need ? n : need);
+        const unsigned b = fr_bits(D, 0u, take);
+        header = take == 32 ? b : ((header << take) | b);
+        hdr_cnt += take;
+        pos = (unsigned)take;
+        if (hdr_cnt < 32) finished = true;
+        else if (fr_good(header)) {
+            pktlen = (int)fr_len(header);
+            woff = (int)((header >> 28) & 0xfu);
+            if (pktlen == 0) {
+                if (lane == 0) msgs[M] = FramerMsg{(unsigned)woff, 0u, B, 0u};
+                ++M;
+                mode = FR_SEARCH;
+            } else {
+                mode = FR_HAVE_HEADER; bits_done = 0; open_off = B; B += (unsigned)pktlen;
+            }
+        } else mode = FR_SEARCH;
+    }
+    if (!finished && mode == FR_HAVE_HEADER) {
+        const unsigned avail = n - pos, rem = (unsigned)(8 * pktlen - bits_done);
+        const unsigned take = avail < rem ? avail : rem;
+        if (lane == 0) jobs[0] = FramerJob{pos, take, open_off, (unsigned)bits_done};
+        bits_done += (int)take;
+        pos += take;
+        if (bits_done < 8 * pktlen) finished = true;
+        else {
+            if (lane == 0) msgs[M] = FramerMsg{(unsigned)woff, (unsigned)pktlen, open_off, 0u};
+            ++M;
+            mode = FR_SEARCH;
+        }
+    }
+    const unsigned M0 = M;                                   // jobs[1 + (message index - M0)] belong to this call's packets
+    // the last packet of the call, to derive the state it leaves: (p, h, message index, pool offset)
+    bool have_last = false;
+    unsigned lp = 0, lh = 0, lm = 0, lo = 0;
+
+    if (!finished) {
+        for (unsigned k = 0; k < nseg; ++k) {
+            const FrSeg sg = segs[k];
+            const unsigned c = uni(sg.cnt), s1 = min((k + 1u) * seg, n);
+            const FrRec *r = recs + (size_t)k * reccap;
+            unsigned acc = c;                                // first accepted record (c = none)
+            if (pos < s1) {
+                for (;;) {
+                    // first record at or after pos
+                    unsigned i = c;
+                    if (pos <= k * seg) i = 0;
+                    else
+                        for (unsigned b = 0; b < c; b += 64u) {
+                            const unsigned idx = b + lane;
+                            const unsigned pv = idx < c ? r[idx].p : 0xffffffffu;
+                            const unsigned long long bal = __ballot(pv >= pos);
+                            if (bal) { i = b + (unsigned)(__ffsll((long long)bal) - 1); break; }
+                        }
+                    bool diverged = false;
+                    if (i > 0) {
+                        const FrRec q = r[i - 1];
+                        diverged = fr_end(uni(q.p), uni(q.h), n) > pos;          // pos inside a speculative packet
+                    }
+                    if (!diverged) { acc = i; break; }
+                    // walk one packet from the true position
+                    const unsigned p = fr_next_flag(F, nwords, pos, s1, lane);
+                    if (p >= s1) { acc = c; break; }         // nothing more starts in this segment
+                    unsigned h;
+                    if (p + 32u > n) h = fr_bits(D, p, (int)(n - p));
+                    else h = fr_bits(D, p, 32);
+                    have_last = true; lp = p; lh = h; lm = M; lo = B;
+                    if (p + 32u <= n && fr_good(h)) {
+                        const unsigned len = fr_len(h), room = n - (p + 32u);
+                        if (lane == 0) {
+                            msgs[M] = FramerMsg{(h >> 28) & 0xfu, len, B, 0u};
+                            jobs[1u + (M - M0)] = FramerJob{p + 32u, min(8u * len, room), B, 0u};
+                        }
+                        ++M; B += len;
+                    }
+                    pos = fr_end(p, h, n);
+                    if (pos >= s1) { acc = c; break; }
+                }
+            }
+            unsigned mb = 0, bb = 0;
+            if (acc < c) {
+                const FrRec a = r[acc], z = r[c - 1];
+                mb = M - uni(a.cmsg); bb = B - uni(a.cbytes);
+                have_last = true; lp = uni(z.p); lh = uni(z.h); lm = mb + uni(z.cmsg); lo = bb + uni(z.cbytes);
+                M += uni(sg.totm) - uni(a.cmsg);
+                B += uni(sg.totb) - uni(a.cbytes);
+                pos = uni(sg.exit);
+            }
+            if (lane == 0) { segs[k].acc = acc; segs[k].mbase = mb; segs[k].bbase = bb; }
+        }
+        // the state the last packet leaves (.cc:119-182)
+        mode = FR_SEARCH;
+        if (have_last && fr_end(lp, lh, n) > n) {
+            if (lp + 32u > n) {                              // header incomplete
+                mode = FR_HAVE_SYNC; header = lh; hdr_cnt = (int)(n - lp);
+            } else {                                         // good header, payload incomplete: the message stays open
+                mode = FR_HAVE_HEADER; pktlen = (int)fr_len(lh); woff = (int)((lh >> 28) & 0xfu);
+                bits_done = (int)(n - (lp + 32u)); open_off = lo;
+                M = lm;                                      // it is the last one: not complete yet
+            }
+        }
+    }
+    if (finished)                                            // nothing of this call's segments is used
+        for (unsigned k = lane; k < nseg; k += 64u) segs[k].acc = segs[k].cnt;
+    if (lane == 0) {
+        S->mode = mode; S->header = header; S->hdr_cnt = hdr_cnt; S->pktlen = pktlen; S->woff = woff;
+        S->bits_done = bits_done; S->msg_count = M; S->pool_used = B; S->open_off = open_off;
+        // every message of this call has its job slot; an open last packet has one more
+        S->njobs = finished ? 1u : (1u + (M - M0) + (mode == FR_HAVE_HEADER ? 1u : 0u));
+        S->pad[0] = M0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+framer_emit_kernel(unsigned n, unsigned reccap, const FrRec *__restrict__ recs, const FrSeg *__restrict__ segs,
+                   const FramerState *S, FramerMsg *msgs, FramerJob *jobs)
+{
+    const unsigned k = blockIdx.x;
+    const FrSeg sg = segs[k];
+    const unsigned M0 = S->pad[0];
+    const FrRec *r = recs + (size_t)k * reccap;
+    for (unsigned j = sg.acc + threadIdx.x; j < sg.cnt; j += 256u) {
+        const FrRec q = r[j];
+        if (q.p + 32u > n || !fr_good(q.h)) continue;
+        const unsigned len = fr_len(q.h), idx = sg.mbase + q.cmsg, off = sg.bbase + q.cbytes;
+        msgs[idx] = FramerMsg{(q.h >> 28) & 0xfu, len, off, 0u};
+        jobs[1u + (idx - M0)] = FramerJob{q.p + 32u, min(8u * len, n - (q.p + 32u)), off, 0u};
+    }
+}
+
 // payload bits -> bytes (.cc:158-162): one lane per packet byte; a byte shared with the previous call's
 // job keeps the bits that are already there
 __global__ void __launch_bounds__(256)
@@ -215,6 +436,7 @@ framer_payload_kernel(const unsigned *__restrict__ D, const FramerState *S, cons
     const unsigned njobs = S->njobs;
     for (unsigned j = blockIdx.x; j < njobs; j += gridDim.x) {
         const FramerJob jb = jobs[j];
+        if (jb.nbits == 0) continue;                                     // (zero-length packet / nothing of it in this call)
         const unsigned first = jb.dst_bit >> 3, last = (jb.dst_bit + jb.nbits - 1) >> 3;
         for (unsigned y = first + threadIdx.x; y <= last; y += 256) {
             const unsigned b0 = max(8u * y, jb.dst_bit), b1 = min(8u * y + 8u, jb.dst_bit + jb.nbits);
@@ -252,7 +474,7 @@ framer_compact_kernel(FramerState *S, unsigned char *pool)
 }  // namespace grhip
 
 struct grhip_framer_sink_1 : HandleBase {
-    DevBuf d_state, d_F, d_D, d_jobs, d_msgs, d_pool;
+    DevBuf d_state, d_F, d_D, d_jobs, d_msgs, d_pool, d_recs, d_segs;
     size_t msg_bound = 0, pool_bound = 4096;     // upper bounds of what un-fetched calls can have produced
     // host copy of the last fetch
     std::vector<FramerMsg> h_msgs;
@@ -291,7 +513,7 @@ void grhip_framer_sink_1_destroy(grhip_framer_sink_1 *h)
 {
     if (!h) return;
     (void)h->bind();
-    h->d_state.release(); h->d_F.release(); h->d_D.release(); h->d_jobs.release(); h->d_msgs.release(); h->d_pool.release();
+    h->d_state.release(); h->d_F.release(); h->d_D.release(); h->d_jobs.release(); h->d_msgs.release(); h->d_pool.release(); h->d_recs.release(); h->d_segs.release();
     h->destroy_base();
     delete h;
 }
@@ -308,9 +530,9 @@ int grhip_framer_sink_1_work_device(grhip_framer_sink_1 *h, int noutput_items, c
     const long long n = noutput_items, nwords = (n + 31) >> 5, nwp = nwords + 2;
     if ((rc = h->d_F.reserve((size_t)nwp * 4))) return rc;
     if ((rc = h->d_D.reserve((size_t)nwp * 4))) return rc;
-    if ((rc = h->d_jobs.reserve((size_t)(n / 32 + 4) * sizeof(FramerJob)))) return rc;
+    if ((rc = h->d_jobs.reserve((size_t)(n / 32 + 8) * sizeof(FramerJob)))) return rc;
     // every packet costs at least 32 items; payload bytes cost 8 items each; one packet of up to 4095 bytes may be open
-    if ((rc = h->grow(h->d_msgs, h->msg_bound * sizeof(FramerMsg), (h->msg_bound + (size_t)n / 32 + 4) * sizeof(FramerMsg), st))) return rc;
+    if ((rc = h->grow(h->d_msgs, h->msg_bound * sizeof(FramerMsg), (h->msg_bound + (size_t)n / 32 + 8) * sizeof(FramerMsg), st))) return rc;
     if ((rc = h->grow(h->d_pool, h->pool_bound, h->pool_bound + (size_t)n / 8 + 4096 + 16, st))) return rc;
     h->msg_bound += (size_t)n / 32 + 2;
     h->pool_bound += (size_t)n / 8 + 4096;
@@ -319,8 +541,30 @@ int grhip_framer_sink_1_work_device(grhip_framer_sink_1 *h, int noutput_items, c
     const unsigned pack_blocks = (unsigned)std::min<long long>((nwp + 255) / 256, 8192);
     hipLaunchKernelGGL(framer_pack_kernel, dim3(pack_blocks), dim3(256), 0, st, d_in, n, h->d_F.as<unsigned>(),
                        h->d_D.as<unsigned>(), nwp);
-    hipLaunchKernelGGL(framer_walk_kernel, dim3(1), dim3(64), 0, st, h->d_F.as<unsigned>(), h->d_D.as<unsigned>(), (unsigned)n,
-                       h->d_state.as<FramerState>(), h->d_msgs.as<FramerMsg>(), h->d_jobs.as<FramerJob>());
+    // items per segment: the fix-up costs about 0.85 us per segment, a segment's own walk about 0.63 us per 1000
+    // items, so the two balance near seg = sqrt(1350 n) (measured, tools/bench_framer.py)
+    long long seg = 4096;
+    while (4 * seg * seg <= 1350 * n && seg < (1ll << 20)) seg <<= 1;
+    if (const char *e = getenv("GRHIP_FRAMER_SEG")) seg = std::max(64ll, atoll(e));       // tuning / test knob
+    const long long nseg = (n + seg - 1) / seg;
+    if (nseg >= 4) {
+        const size_t reccap = (size_t)seg / 32 + 2;
+        if ((rc = h->d_recs.reserve((size_t)nseg * reccap * sizeof(FrRec)))) return rc;
+        if ((rc = h->d_segs.reserve((size_t)nseg * sizeof(FrSeg)))) return rc;
+        hipLaunchKernelGGL(framer_segwalk_kernel, dim3((unsigned)nseg), dim3(64), 0, st, h->d_F.as<unsigned>(),
+                           h->d_D.as<unsigned>(), (unsigned)n, (unsigned)seg, (unsigned)reccap, h->d_recs.as<FrRec>(),
+                           h->d_segs.as<FrSeg>());
+        hipLaunchKernelGGL(framer_fixup_kernel, dim3(1), dim3(64), 0, st, h->d_F.as<unsigned>(), h->d_D.as<unsigned>(),
+                           (unsigned)n, (unsigned)seg, (unsigned)nseg, (unsigned)reccap, h->d_recs.as<FrRec>(),
+                           h->d_segs.as<FrSeg>(), h->d_state.as<FramerState>(), h->d_msgs.as<FramerMsg>(),
+                           h->d_jobs.as<FramerJob>());
+        hipLaunchKernelGGL(framer_emit_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (unsigned)n, (unsigned)reccap,
+                           h->d_recs.as<FrRec>(), h->d_segs.as<FrSeg>(), h->d_state.as<FramerState>(),
+                           h->d_msgs.as<FramerMsg>(), h->d_jobs.as<FramerJob>());
+    } else {
+        hipLaunchKernelGGL(framer_walk_kernel, dim3(1), dim3(64), 0, st, h->d_F.as<unsigned>(), h->d_D.as<unsigned>(),
+                           (unsigned)n, h->d_state.as<FramerState>(), h->d_msgs.as<FramerMsg>(), h->d_jobs.as<FramerJob>());
+    }
     const unsigned pay_blocks = (unsigned)std::min<long long>(n / 256 + 1, 2048);
     hipLaunchKernelGGL(framer_payload_kernel, dim3(pay_blocks), dim3(256), 0, st, h->d_D.as<unsigned>(),
                        h->d_state.as<FramerState>(), h->d_jobs.as<FramerJob>(), h->d_pool.as<unsigned char>());

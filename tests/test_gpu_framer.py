@@ -115,3 +115,20 @@ def test_framer_after_correlator(gpu, po, wl):
     assert got == ref
     # every transmitted packet whose access code was not part of an earlier payload comes out
     assert len(got) >= 35 and all(m in sent for m in got)
+
+
+@pytest.mark.parametrize("seg", [64, 320, 4096, 65536])
+@pytest.mark.parametrize("seed,gap,maxlen", [(20, 200, 64), (21, 30, 10), (22, 3000, 900), (23, 1, 4095), (24, 500, 0)])
+def test_framer_segment_parallel_walk(gpu, po, monkeypatch, seg, seed, gap, maxlen):
+    """long calls take the segment-parallel walk (speculative per-segment walks + serial fix-up); GRHIP_FRAMER_SEG
+    shrinks the segments so that packets straddle many of them and the fix-up's divergence branch is exercised"""
+    monkeypatch.setenv("GRHIP_FRAMER_SEG", str(seg))
+    rng = np.random.default_rng(seed)
+    n = 300_000
+    x = make_stream(rng, n, gap, maxlen, stray_flags=0.004)
+    ref = ref_chunks(po, x, [])
+    assert run_chunks(gpu.framer_sink_1(), x, []) == ref
+    cuts = sorted(int(c) for c in rng.integers(0, n, 4))
+    assert run_chunks(gpu.framer_sink_1(), x, cuts) == ref_chunks(po, x, [])
+    dense = rng.integers(0, 4, 100_000, dtype=np.uint8)
+    assert run_chunks(gpu.framer_sink_1(), dense, [33_333]) == ref_chunks(po, dense, [])
