@@ -635,14 +635,23 @@ class framer_sink_1(_Block):
     def messages(self, stream=None):
         L = lib()
         L.grhip_framer_sink_1_message_count.argtypes = [C.c_void_p, C.c_void_p]
-        L.grhip_framer_sink_1_pop.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int]
+        L.grhip_framer_sink_1_drain.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         n = _check(L.grhip_framer_sink_1_message_count(self._h, _stream(stream)))
-        buf = np.zeros(4096, dtype=np.uint8)
         out = []
-        for _ in range(n):
-            woff = C.c_int(0)
-            ln = _check(L.grhip_framer_sink_1_pop(self._h, C.byref(woff), _ptr(buf), 4096))
-            out.append((woff.value, buf[:ln].tobytes()))
+        while n > 0:
+            k = min(n, 1 << 16)
+            woff = np.zeros(k, dtype=np.int32)
+            lens = np.zeros(k, dtype=np.int32)
+            buf = np.zeros(k * 4096 if k < 64 else max(k * 256, 1 << 20), dtype=np.uint8)
+            got = _check(L.grhip_framer_sink_1_drain(self._h, k, _ptr(woff), _ptr(lens), _ptr(buf), buf.size))
+            if got == 0:                                   # a single payload larger than the share of the buffer
+                buf = np.zeros(4096, dtype=np.uint8)
+                got = _check(L.grhip_framer_sink_1_drain(self._h, 1, _ptr(woff), _ptr(lens), _ptr(buf), buf.size))
+            ends = np.cumsum(lens[:got])
+            raw = buf.tobytes()
+            for i in range(got):
+                out.append((int(woff[i]), raw[ends[i] - lens[i]:ends[i]]))
+            n -= got
         return out
 
 

@@ -11,6 +11,7 @@
 //                             payload jobs and carries the reference's state (partial header, partial
 //                             payload) across calls in device memory;
 //   3. framer_payload_kernel  the payload bytes of all jobs, one lane per byte, from the packed data words.
+// Long calls replace step 2 by the segment-parallel walk further down (framer_segwalk / fixup / emit kernels).
 // Messages (whitener offset = gr_message arg1, payload) collect in a device pool until the host fetches them.
 #include <algorithm>
 #include <cstdlib>
@@ -590,6 +591,8 @@ static int framer_fetch(grhip_framer_sink_1 *h, hipStream_t st)
         // append: payloads re-based onto the host pool
         if (h->h_msgs.empty()) h->h_pool.clear();
         const unsigned base = (unsigned)h->h_pool.size();
+        h->h_msgs.reserve(h->h_msgs.size() + m.size());
+        h->h_pool.reserve(h->h_pool.size() + p.size());
         for (auto &r : m) {
             FramerMsg q = r;
             q.off = (unsigned)h->h_pool.size();
@@ -627,6 +630,28 @@ int grhip_framer_sink_1_pop(grhip_framer_sink_1 *h, int *whitener_offset, unsign
     if (m.len) memcpy(payload, h->h_pool.data() + m.off, m.len);
     ++h->next_msg;
     return (int)m.len;
+}
+
+// pops up to max_msgs messages at once: whitener offsets, lengths, payloads back to back; stops before a message
+// whose payload would not fit.  Returns the number popped.
+int grhip_framer_sink_1_drain(grhip_framer_sink_1 *h, int max_msgs, int *whitener_offsets, int *lengths,
+                              unsigned char *payload, size_t payload_capacity)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (max_msgs < 0 || (max_msgs && (!whitener_offsets || !lengths))) return fail(GRHIP_EINVAL, "bad arguments");
+    int k = 0;
+    size_t used = 0;
+    while (k < max_msgs && h->next_msg < h->h_msgs.size()) {
+        const FramerMsg &m = h->h_msgs[h->next_msg];
+        if (used + m.len > payload_capacity || (m.len && !payload)) break;
+        whitener_offsets[k] = (int)m.woff;
+        lengths[k] = (int)m.len;
+        if (m.len) memcpy(payload + used, h->h_pool.data() + m.off, m.len);
+        used += m.len;
+        ++k;
+        ++h->next_msg;
+    }
+    return k;
 }
 
 int grhip_framer_sink_1_work(grhip_framer_sink_1 *h, int noutput_items, const unsigned char *in)

@@ -367,6 +367,10 @@ GRHIP_API int grhip_framer_sink_1_work_device(grhip_framer_sink_1 *h, int noutpu
 GRHIP_API int grhip_framer_sink_1_message_count(grhip_framer_sink_1 *h, void *stream);
 GRHIP_API int grhip_framer_sink_1_pop(grhip_framer_sink_1 *h, int *whitener_offset, unsigned char *payload,
                                       int capacity);
+/* several messages at once (after message_count): offsets, lengths and the payloads back to back;
+ * stops before a message whose payload would not fit; returns how many were popped */
+GRHIP_API int grhip_framer_sink_1_drain(grhip_framer_sink_1 *h, int max_msgs, int *whitener_offsets, int *lengths,
+                                        unsigned char *payload, size_t payload_capacity);
 
 /* ======================================================================
  * gr_stream_to_streams / gr_streams_to_stream  (the adapters either side of the
