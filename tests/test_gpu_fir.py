@@ -495,3 +495,41 @@ def test_fir_reads_nothing_past_the_guaranteed_items(gpu, po, kind, ntaps, decim
     got = blk.work(n, x)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= TOL * np.abs(ref).max() * 4
+
+
+def test_high_decimation_kernel_random_shapes(gpu, po, wl):
+    """seeded sweep over the shapes the high-decimation direct kernel takes (every power-of-two factor of the
+    decimation selects another LDS layout; output counts around its tiles; two calls per case), for fir_filter_ccf /
+    _ccc and freq_xlating with a real (pre-mix form from 16 taps per phase) and a complex prototype"""
+    rng = np.random.default_rng(777)
+    c = wl.CFG2
+    for case in range(40):
+        decim = int(rng.choice([3, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 48, 64]))
+        ntaps = int(rng.choice([1, 2, decim, decim + 1, 3 * decim - 1, 16 * decim, 16 * decim + 3, 25 * decim, 40 * decim]))
+        ntaps = min(ntaps, 2000)
+        n = int(rng.choice([1, 2, 3, 127, 128, 129, 511, 512, 513, 1000, 2345]))
+        kind = ["ccf", "ccc", "xl_real", "xl_cplx"][case % 4]
+        nin = n * decim + ntaps - 1
+        x = _rand_c(rng, nin)
+        n1 = n // 2
+        if kind in ("ccf", "ccc"):
+            taps = rng.uniform(-1, 1, ntaps).astype(np.float32) if kind == "ccf" else _rand_c(rng, ntaps)
+            blk = (gpu.fir_filter_ccf if kind == "ccf" else gpu.fir_filter_ccc)(decim, taps)
+            ref = (po.fir_ccf if kind == "ccf" else po.fir_ccc)(taps, x, n, decim)
+            bound = np.abs(taps).sum() * np.sqrt(2)
+        else:
+            taps = wl.lowpass_taps(ntaps, 0.4 / decim, 1.0).astype(np.complex64)
+            if kind == "xl_cplx":
+                taps = (taps * np.exp(0.02j * np.arange(ntaps))).astype(np.complex64)
+            blk = gpu.freq_xlating_fir_filter_ccc(decim, taps, c["center_freq"], c["fs"])
+            ref = po.Xlating(decim, taps, c["center_freq"], c["fs"]).work(x, n)
+            bound = np.abs(taps).sum() * np.sqrt(2)
+        blk.set_mode(gpu.MODE_FAST)
+        parts = []
+        if n1 > 0:
+            parts.append(blk.work(n1, x[: n1 * decim + ntaps - 1]))
+        parts.append(blk.work(n - n1, x[n1 * decim:]))
+        got = np.concatenate(parts)
+        assert got.shape == ref.shape, (kind, ntaps, decim, n)
+        err = np.abs(got - ref).max()
+        assert err <= TOL * max(np.abs(ref).max(), 1e-3 * bound), (kind, ntaps, decim, n, err)
