@@ -132,3 +132,17 @@ def test_framer_segment_parallel_walk(gpu, po, monkeypatch, seg, seed, gap, maxl
     assert run_chunks(gpu.framer_sink_1(), x, cuts) == ref_chunks(po, x, [])
     dense = rng.integers(0, 4, 100_000, dtype=np.uint8)
     assert run_chunks(gpu.framer_sink_1(), dense, [33_333]) == ref_chunks(po, dense, [])
+
+
+def test_framer_parallel_walk_inside_a_long_packet(gpu, po, monkeypatch):
+    """calls that begin and end inside one 4095-byte packet, on the segment-parallel path (the speculative
+    segments of such a call must contribute nothing), then packets again"""
+    monkeypatch.setenv("GRHIP_FRAMER_SEG", "64")
+    rng = np.random.default_rng(31)
+    x = make_stream(rng, 120_000, 5, 4095, bad=0.0, stray_flags=0.01)
+    ref = ref_chunks(po, x, [])
+    assert any(len(m[1]) > 2000 for m in ref)
+    cuts = list(range(700, len(x), 1000))                     # 1000-item calls: 16 segments each
+    assert run_chunks(gpu.framer_sink_1(), x, cuts) == ref
+    cuts = list(range(31, len(x), 257))                       # header bits split across calls as well
+    assert run_chunks(gpu.framer_sink_1(), x, cuts) == ref
