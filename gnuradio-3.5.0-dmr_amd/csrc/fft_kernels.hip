@@ -397,38 +397,55 @@ __global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a)
         const float2 *x = a.in + (long long)j * a.stride;
         const long long lim = a.nout + a.tpf;          // tpf history items + nout new ones per stream
         float2 *dst = xs + (size_t)j * XS;
-        for (int m = ln; m < TT + tpfp; m += 64) {
-            const long long g = t0 + 1 + m;
-            dst[m + (m >> 3)] = (g < lim) ? x[g] : make_float2(0.f, 0.f);
+        // eight independent loads in flight per lane (one load per loop trip would leave the wave waiting for
+        // HBM latency nine times per tile)
+        const int tot = TT + tpfp;
+        for (int mb = ln; mb < tot; mb += 64 * 8) {
+            float2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = mb + 64 * i;
+                const long long g = t0 + 1 + m;
+                v[i] = make_float2(0.f, 0.f);
+                if (m < tot && g < lim) v[i] = x[g];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = mb + 64 * i;
+                if (m < tot) dst[m + (m >> 3)] = v[i];
+            }
         }
     }
     __builtin_amdgcn_s_waitcnt(0);                     // wave-private region: no workgroup barrier needed
     __builtin_amdgcn_wave_barrier();
 
     // ---- FIR, 8 output vectors per lane
-    float2 acc[R];
+    // (re, im) pairs as 2-vectors: one v_pk_fma_f32 per tap and output instead of two v_fma_f32
+    typedef float pfb_f32x2 __attribute__((ext_vector_type(2)));
+    pfb_f32x2 accv[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
+    for (int r = 0; r < R; ++r) accv[r] = (pfb_f32x2){0.f, 0.f};
     {
         const float2 *xp = xs + (size_t)j * XS + ln * R + ln;      // slot of m = 8 ln
-        float2 w[R];
+        pfb_f32x2 w[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) w[q] = xp[q];
+        for (int q = 0; q < R; ++q) { const float2 v = xp[q]; w[q] = (pfb_f32x2){v.x, v.y}; }
         for (int q0 = 0; q0 < tpfp; q0 += R) {
             const int nxt = q0 + R + (q0 >> 3) + 1;
 #pragma unroll
             for (int qq = 0; qq < R; ++qq) {
                 const float h = (q0 + qq < a.tpf) ? taps[q0 + qq] : 0.f;
+                const pfb_f32x2 hv = (pfb_f32x2){h, h};
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float2 xv = w[(qq + r) & (R - 1)];
-                    acc[r].x = __builtin_fmaf(h, xv.x, acc[r].x);
-                    acc[r].y = __builtin_fmaf(h, xv.y, acc[r].y);
-                }
-                w[qq] = xp[nxt + qq];
+                for (int r = 0; r < R; ++r) accv[r] = __builtin_elementwise_fma(hv, w[(qq + r) & (R - 1)], accv[r]);
+                const float2 v = xp[nxt + qq];
+                w[qq] = (pfb_f32x2){v.x, v.y};
             }
         }
     }
+    float2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float2(accv[r].x, accv[r].y);
     // ---- to IFFT slot M-1-j, transposed: sl[slot][t_local]
     __syncthreads();                                   // sl aliases xs
     {
