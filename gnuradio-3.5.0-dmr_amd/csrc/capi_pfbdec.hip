@@ -43,7 +43,20 @@ pfb_dec_kernel(const float2 *__restrict__ in, long long stride, int M, int tpf4,
         const int j = M - 1 - s;                 // stream s feeds filter j (.cc:146-149)
         const float2 *x = in + (long long)s * stride + base;
         if (s) __syncthreads();
-        for (int u = t; u < ns; u += 256) xs[u] = base + u < avail ? x[u] : make_float2(0.f, 0.f);
+        for (int ub = t; ub < ns; ub += 256 * 8) {          // eight independent loads in flight per lane
+            float2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int u = ub + 256 * i;
+                v[i] = make_float2(0.f, 0.f);
+                if (u < ns && base + u < avail) v[i] = x[u];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int u = ub + 256 * i;
+                if (u < ns) xs[u] = v[i];
+            }
+        }
         __syncthreads();
         // lane t: outputs 4t .. 4t+3; w[] slides over x[4t + k .. 4t + k + 7], four taps per step
         f32x2 f[4], w[8];
