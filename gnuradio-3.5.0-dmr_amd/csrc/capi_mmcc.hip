@@ -71,9 +71,16 @@ mmcc_kernel(MMccState *__restrict__ state, int noutput_items, int ninput_items, 
 
     while (!done) {
         const int base = ii, obase = oo;
-        for (int i = lane; i < MMC_CH; i += 64) {
-            const long long g = (long long)base + i;
-            s_in[i] = (g >= 0 && g < ninput_items) ? x[g] : make_float2(0.f, 0.f);
+        for (int ib = lane; ib < MMC_CH; ib += 64 * 16) {    // sixteen independent loads in flight per lane
+            float2 v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const long long g = (long long)base + ib + 64 * q;
+                v[q] = make_float2(0.f, 0.f);
+                if (g >= 0 && g < ninput_items) v[q] = x[g];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s_in[ib + 64 * q] = v[q];
         }
         __syncthreads();
         const int lim_i = base + MMC_CH - MMC_NTAPS;

@@ -66,9 +66,18 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
 
     while (!done) {
         const int base = ii, obase = oo;
-        for (int i = lane; i < MM_CH; i += 64) {
-            long long g = (long long)base + i;
-            s_in[i] = (g >= 0 && g < ninput_items) ? x[g] : 0.f;
+        // sixteen independent loads in flight per lane: one load per loop trip would make the lone wave wait for
+        // memory latency 64 times per window
+        for (int ib = lane; ib < MM_CH; ib += 64 * 16) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const long long g = (long long)base + ib + 64 * q;
+                v[q] = 0.f;
+                if (g >= 0 && g < ninput_items) v[q] = x[g];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s_in[ib + 64 * q] = v[q];
         }
         __syncthreads();
         const int lim = base + MM_CH - MM_NTAPS;
