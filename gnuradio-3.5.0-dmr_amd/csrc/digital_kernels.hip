@@ -158,10 +158,20 @@ pager_slicer_kernel(float *__restrict__ d_avg, float alpha, float beta, const fl
     float avg = d_avg[s];
     for (long long base = 0; base < n; base += PS_CH) {
         const int m = (int)(n - base < PS_CH ? n - base : PS_CH);
-        for (int i = lane; i < m; i += 64) {
-            const float v = x[base + i];
-            s_x[i] = v;
-            s_t[i] = v * alpha;
+        {   // the whole window with all of a lane's loads in flight at once (PS_CH / 64 of them)
+            float v[PS_CH / 64];
+#pragma unroll
+            for (int q = 0; q < PS_CH / 64; ++q) {
+                const int i = lane + 64 * q;
+                v[q] = 0.f;
+                if (i < m) v[q] = x[base + i];
+            }
+#pragma unroll
+            for (int q = 0; q < PS_CH / 64; ++q) {
+                const int i = lane + 64 * q;
+                s_x[i] = v[q];
+                s_t[i] = v[q] * alpha;
+            }
         }
         __syncthreads();
         for (int i = 0; i < m; ++i) {

@@ -89,6 +89,14 @@ ob = torch.empty(n, dtype=torch.uint8, device=dev)
 ca = g.correlate_access_code_bb(wl.access_code_string(), 4)
 report("correlate_access_code_bb", timeit(lambda: ca.work_device(n, bits, ob, st)), n, 2, "Mbits/s")
 
+# pager_slicer_fb: a serial DC tracker, one wavefront per stream: the rate of ONE stream
+ns_ = 4_000_000
+sx = torch.randn(ns_, device=dev)
+so = torch.empty(ns_, dtype=torch.uint8, device=dev)
+ps = g.pager_slicer_fb(0.002)
+report("pager_slicer_fb one stream of 4 M symbols (one wavefront, latency-bound)",
+       timeit(lambda: ps.work_device(ns_, sx, so, st), reps=5, ramp_s=0.05), ns_, 5, "Msymbols/s")
+
 # cfg3: fft_vcc 4096-pt over 2^24 samples; pfb_channelizer M=8, 256-tap prototype, 2^24 samples
 N, nvec = 4096, 4096
 xv = torch.randn((N * nvec, 2), device=dev)
