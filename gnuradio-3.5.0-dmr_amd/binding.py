@@ -449,6 +449,12 @@ class binary_slicer_fb(_Block):
         n = _check(L.grhip_binary_slicer_fb_work(self._h, int(noutput_items), _ptr(x), _ptr(out)))
         return out[:n]
 
+    def work_device(self, noutput_items, d_in, d_out, stream=None):
+        L = lib()
+        L.grhip_binary_slicer_fb_work_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        return _check(L.grhip_binary_slicer_fb_work_device(self._h, int(noutput_items), _devptr(d_in), _devptr(d_out),
+                                                           _stream(stream)))
+
 
 class pager_slicer_fb(_Block):
     """pager.slicer_fb(alpha): DC-tracking 4-level slicer (gr-pager/lib/pager_slicer_fb.cc)"""

@@ -244,3 +244,24 @@ def test_remaining_harness_adapters(gpu):
     assert h2.work_device(4096, d, o, st) == 1000 and h2.work_device(4096, d, o, st) == -1
     st.synchronize()
     assert torch.equal(o[:1000], d[:1000]) and float(o[1000:].abs().sum()) == 0.0
+
+
+def test_binary_slicer_vector_and_tail_paths(gpu, po):
+    """16 items per lane on aligned buffers, scalar tail, scalar path on unaligned device pointers; -0.0 slices to 1
+    (digital_binary_slicer_fb.cc:54-56: x >= 0)"""
+    import torch
+    rng = np.random.default_rng(8)
+    for n in (1, 15, 16, 17, 4099, 100_003):
+        x = rng.standard_normal(n).astype(np.float32)
+        x[::7] = 0.0
+        x[3::11] = -0.0
+        assert np.array_equal(gpu.binary_slicer_fb().work(n, x), po.binary_slicer_fb(x))
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    x = rng.standard_normal(5000).astype(np.float32)
+    d = torch.from_numpy(x).to(dev)
+    o = torch.zeros(5001, dtype=torch.uint8, device=dev)
+    blk = gpu.binary_slicer_fb()
+    assert blk.work_device(4999, d[1:], o[1:], st) == 4999           # both pointers off the 16-byte grid
+    st.synchronize()
+    assert np.array_equal(o[1:5000].cpu().numpy(), po.binary_slicer_fb(x[1:]))

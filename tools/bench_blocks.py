@@ -89,6 +89,13 @@ ob = torch.empty(n, dtype=torch.uint8, device=dev)
 ca = g.correlate_access_code_bb(wl.access_code_string(), 4)
 report("correlate_access_code_bb", timeit(lambda: ca.work_device(n, bits, ob, st)), n, 2, "Mbits/s")
 
+# binary_slicer_fb on its own (the chain fuses it into the correlator): 5 B per item
+nb_ = 128_000_000
+bx = torch.randn(nb_, device=dev)
+bo = torch.empty(nb_, dtype=torch.uint8, device=dev)
+bs = g.binary_slicer_fb()
+report("binary_slicer_fb", timeit(lambda: bs.work_device(nb_, bx, bo, st), reps=20), nb_, 5)
+
 # pager_slicer_fb: a serial DC tracker, one wavefront per stream: the rate of ONE stream
 ns_ = 4_000_000
 sx = torch.randn(ns_, device=dev)
