@@ -218,7 +218,7 @@ framer_walk_kernel(const unsigned *__restrict__ F, const unsigned *__restrict__ 
 // itself until the two coincide.  framer_emit_kernel finally turns the accepted records into message records
 // and payload jobs at the indices the fix-up assigned.
 struct FrRec { unsigned p, h, cmsg, cbytes; };   // flag position, header bits, messages / payload bytes before it in the segment
-struct FrSeg { unsigned cnt, totm, totb, exit, acc, mbase, bbase, pad; };
+struct FrSeg { unsigned cnt, totm, totb, exit, acc, mbase, bbase, lastp, lasth, lastcm, lastcb, firstp; };   // last*: the segment's last record; firstp: its first flag
 
 __device__ inline bool fr_good(unsigned h) { return ((h >> 16) ^ (h & 0xffffu)) == 0; }
 __device__ inline unsigned fr_len(unsigned h) { return (h >> 16) & 0x0fffu; }
@@ -256,23 +256,28 @@ framer_segwalk_kernel(const unsigned *__restrict__ F, const unsigned *__restrict
     const unsigned nwords = (n + 31u) >> 5;
     const unsigned s0 = k * seg, s1 = min(s0 + seg, n);
     FrRec *r = recs + (size_t)k * reccap;
-    unsigned pos = s0, cnt = 0, cm = 0, cb = 0;
+    unsigned pos = s0, cnt = 0, cm = 0, cb = 0, lp = 0, lh = 0, lcm = 0, lcb = 0, fp = 0;
     while (pos < s1) {
         const unsigned p = fr_next_flag(F, nwords, pos, s1, lane);
         if (p >= s1) { pos = s1; break; }
         if (p + 32u > n) {                                  // header cut off by the end of the call
-            if (lane == 0) r[cnt] = FrRec{p, fr_bits(D, p, (int)(n - p)), cm, cb};
+            const unsigned hb = fr_bits(D, p, (int)(n - p));
+            if (lane == 0) r[cnt] = FrRec{p, hb, cm, cb};
+            if (cnt == 0) fp = p;
+            lp = p; lh = hb; lcm = cm; lcb = cb;
             ++cnt;
             pos = p + 32u;
             break;
         }
         const unsigned h = fr_bits(D, p, 32);
         if (lane == 0) r[cnt] = FrRec{p, h, cm, cb};
+        if (cnt == 0) fp = p;
+        lp = p; lh = h; lcm = cm; lcb = cb;
         ++cnt;
         pos = p + 32u;
         if (fr_good(h)) { ++cm; cb += fr_len(h); pos += 8u * fr_len(h); }
     }
-    if (lane == 0) segs[k] = FrSeg{cnt, cm, cb, pos, 0u, 0u, 0u, 0u};
+    if (lane == 0) segs[k] = FrSeg{cnt, cm, cb, pos, 0u, 0u, 0u, lp, lh, lcm, lcb, fp};
 }
 
 // where the search resumes after the packet of record (p, h); a header cut off by the end of the call ends behind it
@@ -335,58 +340,76 @@ framer_fixup_kernel(const unsigned *__restrict__ F, const unsigned *__restrict__
     unsigned lp = 0, lh = 0, lm = 0, lo = 0;
 
     if (!finished) {
-        for (unsigned k = 0; k < nseg; ++k) {
-            const FrSeg sg = segs[k];
-            const unsigned c = uni(sg.cnt), s1 = min((k + 1u) * seg, n);
-            const FrRec *r = recs + (size_t)k * reccap;
-            unsigned acc = c;                                // first accepted record (c = none)
-            if (pos < s1) {
-                for (;;) {
-                    // first record at or after pos
-                    unsigned i = c;
-                    if (pos <= k * seg) i = 0;
-                    else
+        for (unsigned kb = 0; kb < nseg; kb += 64u) {
+            // the descriptors of 64 segments, one per lane: the common case below needs nothing else
+            FrSeg mine = FrSeg{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            if (kb + lane < nseg) mine = segs[kb + lane];
+            unsigned my_acc = 0, my_mb = 0, my_bb = 0;
+            const unsigned kend = min(64u, nseg - kb);
+            for (unsigned kk = 0; kk < kend; ++kk) {
+                const unsigned k = kb + kk;
+                const int kl = (int)kk;
+                const unsigned c = __builtin_amdgcn_readlane(mine.cnt, kl), s1 = min((k + 1u) * seg, n);
+                unsigned acc = c, mb = 0, bb = 0;            // first accepted record (c = none)
+                if (c != 0u && pos <= __builtin_amdgcn_readlane(mine.firstp, kl)) {
+                    // the search resumes at or before the segment's first flag (no flag lies between the segment's
+                    // start and it): both walks take that flag next, the whole segment is taken over
+                    acc = 0; mb = M; bb = B;
+                    have_last = true;
+                    lp = __builtin_amdgcn_readlane(mine.lastp, kl); lh = __builtin_amdgcn_readlane(mine.lasth, kl);
+                    lm = M + __builtin_amdgcn_readlane(mine.lastcm, kl); lo = B + __builtin_amdgcn_readlane(mine.lastcb, kl);
+                    M += __builtin_amdgcn_readlane(mine.totm, kl);
+                    B += __builtin_amdgcn_readlane(mine.totb, kl);
+                    pos = __builtin_amdgcn_readlane(mine.exit, kl);
+                } else if (c != 0u && pos < s1) {
+                    const FrRec *r = recs + (size_t)k * reccap;
+                    for (;;) {
+                        // first record at or after pos
+                        unsigned i = c;
                         for (unsigned b = 0; b < c; b += 64u) {
                             const unsigned idx = b + lane;
                             const unsigned pv = idx < c ? r[idx].p : 0xffffffffu;
                             const unsigned long long bal = __ballot(pv >= pos);
                             if (bal) { i = b + (unsigned)(__ffsll((long long)bal) - 1); break; }
                         }
-                    bool diverged = false;
-                    if (i > 0) {
-                        const FrRec q = r[i - 1];
-                        diverged = fr_end(uni(q.p), uni(q.h), n) > pos;          // pos inside a speculative packet
-                    }
-                    if (!diverged) { acc = i; break; }
-                    // walk one packet from the true position
-                    const unsigned p = fr_next_flag(F, nwords, pos, s1, lane);
-                    if (p >= s1) { acc = c; break; }         // nothing more starts in this segment
-                    unsigned h;
-                    if (p + 32u > n) h = fr_bits(D, p, (int)(n - p));
-                    else h = fr_bits(D, p, 32);
-                    have_last = true; lp = p; lh = h; lm = M; lo = B;
-                    if (p + 32u <= n && fr_good(h)) {
-                        const unsigned len = fr_len(h), room = n - (p + 32u);
-                        if (lane == 0) {
-                            msgs[M] = FramerMsg{(h >> 28) & 0xfu, len, B, 0u};
-                            jobs[1u + (M - M0)] = FramerJob{p + 32u, min(8u * len, room), B, 0u};
+                        bool diverged = false;
+                        if (i > 0) {
+                            const FrRec q = r[i - 1];
+                            diverged = fr_end(uni(q.p), uni(q.h), n) > pos;      // pos inside a speculative packet
                         }
-                        ++M; B += len;
+                        if (!diverged) { acc = i; break; }
+                        // walk one packet from the true position
+                        const unsigned p = fr_next_flag(F, nwords, pos, s1, lane);
+                        if (p >= s1) { acc = c; break; }     // nothing more starts in this segment
+                        unsigned h;
+                        if (p + 32u > n) h = fr_bits(D, p, (int)(n - p));
+                        else h = fr_bits(D, p, 32);
+                        have_last = true; lp = p; lh = h; lm = M; lo = B;
+                        if (p + 32u <= n && fr_good(h)) {
+                            const unsigned len = fr_len(h), room = n - (p + 32u);
+                            if (lane == 0) {
+                                msgs[M] = FramerMsg{(h >> 28) & 0xfu, len, B, 0u};
+                                jobs[1u + (M - M0)] = FramerJob{p + 32u, min(8u * len, room), B, 0u};
+                            }
+                            ++M; B += len;
+                        }
+                        pos = fr_end(p, h, n);
+                        if (pos >= s1) { acc = c; break; }
                     }
-                    pos = fr_end(p, h, n);
-                    if (pos >= s1) { acc = c; break; }
+                    if (acc < c) {
+                        const FrRec a = r[acc];
+                        mb = M - uni(a.cmsg); bb = B - uni(a.cbytes);
+                        have_last = true;
+                        lp = __builtin_amdgcn_readlane(mine.lastp, kl); lh = __builtin_amdgcn_readlane(mine.lasth, kl);
+                        lm = mb + __builtin_amdgcn_readlane(mine.lastcm, kl); lo = bb + __builtin_amdgcn_readlane(mine.lastcb, kl);
+                        M += __builtin_amdgcn_readlane(mine.totm, kl) - uni(a.cmsg);
+                        B += __builtin_amdgcn_readlane(mine.totb, kl) - uni(a.cbytes);
+                        pos = __builtin_amdgcn_readlane(mine.exit, kl);
+                    }
                 }
+                if (lane == kk) { my_acc = acc; my_mb = mb; my_bb = bb; }
             }
-            unsigned mb = 0, bb = 0;
-            if (acc < c) {
-                const FrRec a = r[acc], z = r[c - 1];
-                mb = M - uni(a.cmsg); bb = B - uni(a.cbytes);
-                have_last = true; lp = uni(z.p); lh = uni(z.h); lm = mb + uni(z.cmsg); lo = bb + uni(z.cbytes);
-                M += uni(sg.totm) - uni(a.cmsg);
-                B += uni(sg.totb) - uni(a.cbytes);
-                pos = uni(sg.exit);
-            }
-            if (lane == 0) { segs[k].acc = acc; segs[k].mbase = mb; segs[k].bbase = bb; }
+            if (kb + lane < nseg) { segs[kb + lane].acc = my_acc; segs[kb + lane].mbase = my_mb; segs[kb + lane].bbase = my_bb; }
         }
         // the state the last packet leaves (.cc:119-182)
         mode = FR_SEARCH;
@@ -542,10 +565,10 @@ int grhip_framer_sink_1_work_device(grhip_framer_sink_1 *h, int noutput_items, c
     const unsigned pack_blocks = (unsigned)std::min<long long>((nwp + 255) / 256, 8192);
     hipLaunchKernelGGL(framer_pack_kernel, dim3(pack_blocks), dim3(256), 0, st, d_in, n, h->d_F.as<unsigned>(),
                        h->d_D.as<unsigned>(), nwp);
-    // items per segment: the fix-up costs about 0.85 us per segment, a segment's own walk about 0.63 us per 1000
-    // items, so the two balance near seg = sqrt(1350 n) (measured, tools/bench_framer.py)
+    // items per segment: the fix-up costs about 0.1 us per segment it can take over wholesale, a segment's own
+    // walk about 0.63 us per 1000 items, so the two balance near seg = sqrt(160 n) (tools/bench_framer.py)
     long long seg = 4096;
-    while (4 * seg * seg <= 1350 * n && seg < (1ll << 20)) seg <<= 1;
+    while (4 * seg * seg <= 160 * n && seg < (1ll << 20)) seg <<= 1;
     if (const char *e = getenv("GRHIP_FRAMER_SEG")) seg = std::max(64ll, atoll(e));       // tuning / test knob
     const long long nseg = (n + seg - 1) / seg;
     if (nseg >= 4) {
