@@ -51,7 +51,76 @@ def parse():
     ap.add_argument("--per-capture-launch", action="store_true",
                     help="one work_device() call per capture (block API) instead of one batched launch")
     ap.add_argument("--cpu-samples", type=int, default=10_000_000)
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU-only self-test of the N-rank launch path (gloo, a stub step that touches no GPU): "
+                         "used by tests/test_bench_launcher.py; the line it prints is labelled as a stub")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher around it: start N copies of this
+    script, one rank per GPU, as CHILD processes (never os.exec*), before this process has
+    imported torch or touched HIP.  Rank 0's JSON line is forwarded; any child failing
+    fails the run."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(a.gpus),
+                    "LOCAL_WORLD_SIZE": str(a.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit("bench.py: rank(s) failed: %s" % bad)
+
+
+def launcher_selftest(a):
+    """world_size ranks on gloo, a stub step (no GPU, no kernel): exercises exactly the
+    launch / rendezvous / sharding / max-over-ranks / rank-0-prints path of the real run."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ["GRHIP_NO_TORCH_PRELOAD"] = "1"
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    g = grhip_loader.import_grhip()
+    from grhip import dist as gd
+    proto = gd.broadcast_taps(g.workload.cfg2_proto_taps() if rank == 0 else np.zeros(1, np.complex64), dist)
+    mine = gd.shard_streams(world * a.captures, rank, world)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.001 * (1 + rank))
+    elapsed = gd.max_over_ranks(time.perf_counter() - t0, dist)
+    seen = [None] * world
+    if world > 1:
+        dist.all_gather_object(seen, (rank, int(os.environ.get("LOCAL_RANK", "-1")), mine, os.getpid(), len(proto)))
+    else:
+        seen = [(rank, 0, mine, os.getpid(), len(proto))]
+    if rank == 0:
+        print(json.dumps({"metric": "STUB launcher self-test (gloo, no GPU work; not a measurement)",
+                          "value": 0.0, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": elapsed / max(a.steps, 1) * 1e3,
+                          "ranks": seen}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def synth_captures(torch, wl, n_caps, n_samples, first_stream_id, device):
@@ -135,6 +204,15 @@ def measured_traffic(captures, samples, launches_per_step):
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torchrun around us: be the launcher (before torch / HIP are touched in this process)
+        return launch_ranks(a)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (a.gpus, os.environ["WORLD_SIZE"]))
+    if a.launcher_selftest:
+        return launcher_selftest(a)
     import torch
     import torch.distributed as dist
 

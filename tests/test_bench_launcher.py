@@ -1,0 +1,49 @@
+"""`python bench.py --gpus N` must itself start N ranks.  CPU test of that launch
+path with N = 2: gloo, a stub step (no GPU), everything else -- child processes, rendezvous on
+127.0.0.1, taps broadcast, capture sharding, max-over-ranks, rank 0 printing ONE line -- as in
+the real run."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_gpus_2_launches_two_ranks():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--captures", "4", "--launcher-selftest"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                     # ONE line, from rank 0
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3
+    ranks = sorted(res["ranks"])
+    assert [x[0] for x in ranks] == [0, 1]               # two distinct ranks reported ...
+    assert [x[1] for x in ranks] == [0, 1]               # ... on two distinct local devices
+    assert ranks[0][3] != ranks[1][3]                    # ... in two processes
+    assert ranks[0][2] == [0, 1, 2, 3] and ranks[1][2] == [4, 5, 6, 7]    # weak scaling: 4 captures per rank
+    assert ranks[0][4] == ranks[1][4] == 256             # rank 1 got rank 0's taps
+    assert res["ms_per_step"] >= 2.0                     # MAX over ranks (rank 1 sleeps 2 ms per step)
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "2", "--launcher-selftest"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_failing_rank_fails_the_run():
+    # the real (GPU) path on a box without a GPU: every rank exits non-zero, so must the launcher
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    import torch
+    if torch.cuda.is_available():
+        return
+    assert r.returncode != 0
