@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--per-capture-launch", action="store_true",
                     help="one work_device() call per capture (block API) instead of one batched launch")
     ap.add_argument("--cpu-samples", type=int, default=10_000_000)
+    ap.add_argument("--engine", choices=["fast", "fast_valu"], default="fast",
+                    help="fast: GRHIP_MODE_FAST (matrix-core FIR engine); fast_valu: f32 vector FMAs only")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU-only self-test of the N-rank launch path (gloo, a stub step that touches no GPU): "
                          "used by tests/test_bench_launcher.py; the line it prints is labelled as a stub")
@@ -187,19 +189,22 @@ def cpu_baseline(wl, x_host, proto, repeats=2):
     return res
 
 
-def measured_traffic(captures, samples, launches_per_step):
+def measured_traffic(kernel, captures, samples, launches_per_step):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
     passes (profiles/traffic.json: FETCH_SIZE doubled per the gfx950 correction for
-    16-byte coalesced streaming reads, + WRITE_SIZE), only when it was collected for
-    this exact configuration; otherwise null."""
+    16-byte coalesced streaming reads, + WRITE_SIZE).  PMC counters cannot be read from
+    inside this process, so the figure is a committed measurement: it is reported only when
+    it was collected for this exact kernel and configuration (its provenance goes into
+    `traffic_source`); otherwise null."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        if t["captures"] == captures and t["samples"] == samples and launches_per_step == 1:
-            return t["hbm_bytes_per_launch"]
+        if (t.get("kernel") == kernel and t["captures"] == captures and t["samples"] == samples
+                and launches_per_step == 1):
+            return t["hbm_bytes_per_launch"], "profiles/traffic.json (%s)" % t.get("collected", "?")
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -254,6 +259,7 @@ def main():
     out = torch.empty((B, orow), dtype=torch.float32, device=dev)
 
     blk = g.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], device=local_rank)
+    blk.set_mode(g.MODE_FAST if a.engine == "fast" else g.MODE_FAST_VALU)
     # a real (non-null) stream: the kernels, and the events that time them, all go here
     stream = torch.cuda.Stream(device=dev)
     launches_per_step = 1 if not a.per_capture_launch else B
@@ -309,6 +315,14 @@ def main():
         alg_bytes = (8.0 + 4.0 / c["decim"]) * n * (B / launches_per_step)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         flops = (2.0 * 2.0 * c["ntaps"] / c["decim"] + 8.0) * n * (B / launches_per_step)   # pre-mix + real-tap MACs
+        if a.engine == "fast":
+            kname = "fir_mfma_kernel<D=4,KS=10,premix,demod>"
+            # matrix engine: 30 v_mfma_f32_16x16x32_f16 (16384 flop each) per 16 outputs x 8 segments = 512 input samples
+            mfma_flops = 30 * 16384.0 / 512.0 * n * (B / launches_per_step)
+        else:
+            kname = "fir_tiled_kernel<D=4,premix,demod>"
+            mfma_flops = 0.0
+        traffic, traffic_src = measured_traffic(kname, B, n, launches_per_step)
         res = {
             "metric": "Msamples/s through FIR->demod chain @256 taps",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -317,13 +331,16 @@ def main():
             "config": {"workload": "freq_xlating_fir_filter_ccc 256-tap decim=4 + quadrature_demod_cf, "
                                    "10 MS/s synthetic 4FSK IQ", "captures_per_gpu_per_step": B,
                        "samples_per_capture": n, "sharding": "independent captures per rank, "
-                       "RCCL broadcast of taps only", "clock_ramp_ms_untimed": a.ramp_ms},
-            "roofline": {"bound": "hbm", "kernel": "fir_tiled_kernel<D=4,premix,demod>",
+                       "RCCL broadcast of taps only", "clock_ramp_ms_untimed": a.ramp_ms,
+                       "engine": "GRHIP_MODE_FAST (banded-Toeplitz FIR on the matrix cores, split binary16, f32 "
+                                 "accumulation)" if a.engine == "fast" else "GRHIP_MODE_FAST_VALU (f32 vector FMAs)"},
+            "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, n, launches_per_step),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "valu_tflops": flops / (k_ms * 1e-3) / 1e12,
-                         "valu_frac_of_fp32_peak": flops / (k_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS},
+                         "fir_equivalent_f32_tflops": flops / (k_ms * 1e-3) / 1e12,
+                         "mfma_f16_tflops": mfma_flops / (k_ms * 1e-3) / 1e12,
+                         "frac_of_f16_mfma_peak": mfma_flops / (k_ms * 1e-3) / 1e12 / 2500.0},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, x0_host[: a.cpu_samples], proto)

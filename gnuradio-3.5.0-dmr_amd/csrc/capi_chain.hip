@@ -121,8 +121,8 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
     const long long hist = h->core.ntaps > 0 ? h->core.ntaps - 1 : 0;
     const float2 *x = (const float2 *)d_in - hist;
     float2 *ys = h->d_ystate.as<float2>();
-    if (h->mode == GRHIP_MODE_FAST) {
-        rc = h->core.run(GRHIP_MODE_FAST, x, hist + (long long)n_samples, n_out, nullptr, h->d_demod.as<float>(),
+    if (mode_fast(h->mode)) {
+        rc = h->core.run(h->mode, x, hist + (long long)n_samples, n_out, nullptr, h->d_demod.as<float>(),
                          h->gain, ys, ys + S, h->tabs->atan_tab, st, h->S, (long long)stream_stride_items, hist,
                          (long long)h->out_stride);
         if (rc) return rc;
@@ -160,7 +160,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
 
 int grhip_dmr_chain_set_mode(grhip_dmr_chain *h, int mode)
 {
-    if (!h || (mode != GRHIP_MODE_FAST && mode != GRHIP_MODE_GENERIC)) return fail(GRHIP_EINVAL, "bad mode");
+    if (!h || !mode_valid(mode)) return fail(GRHIP_EINVAL, "bad mode");
     h->mode = mode;
     return GRHIP_OK;
 }

@@ -34,7 +34,8 @@ int default_mode()
     int m = g_mode.load();
     if (m >= 0) return m;
     const char *e = getenv("GRHIP_MODE");
-    m = (e && (!strcmp(e, "generic") || !strcmp(e, "1"))) ? GRHIP_MODE_GENERIC : GRHIP_MODE_FAST;
+    m = (e && (!strcmp(e, "generic") || !strcmp(e, "1"))) ? GRHIP_MODE_GENERIC
+        : (e && (!strcmp(e, "fast_valu") || !strcmp(e, "2"))) ? GRHIP_MODE_FAST_VALU : GRHIP_MODE_FAST;
     g_mode.store(m);
     return m;
 }
@@ -131,7 +132,7 @@ int grhip_device_synchronize(int device)
 
 int grhip_set_default_mode(int mode)
 {
-    if (mode != GRHIP_MODE_FAST && mode != GRHIP_MODE_GENERIC) return fail(GRHIP_EINVAL, "bad mode %d", mode);
+    if (!mode_valid(mode)) return fail(GRHIP_EINVAL, "bad mode %d", mode);
     g_mode.store(mode);
     return GRHIP_OK;
 }

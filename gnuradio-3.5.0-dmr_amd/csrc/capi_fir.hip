@@ -6,6 +6,7 @@
 #include "fft_kernels.h"
 #include "fir_kernels.h"
 #include "grhip_internal.h"
+#include "mfma_tables.h"
 #include "xlating_core.h"
 
 using namespace grhip;
@@ -34,6 +35,21 @@ static int upload(DevBuf &b, const void *src, size_t bytes)
     int rc = b.reserve(bytes ? bytes : 16);
     if (rc) return rc;
     if (bytes) GRHIP_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return GRHIP_OK;
+}
+
+// ---- operand tables of the matrix-core engine (mfma_tables.h) ---------------------
+// real taps c[k] multiplying x[nD + k]; both alignment parities
+static int build_mfma_taps(const float *c, int T, int D, DevBuf (&dA)[2], int *kexp)
+{
+    const int KS = mf::ksteps_inst(D, T);
+    *kexp = mf::tap_scale_exp(c, T);
+    for (int off = 0; off < 2; ++off) {
+        std::vector<uint16_t> A;
+        mf::build_A(c, T, D, KS, off, *kexp, A);
+        int rc = upload(dA[off], A.data(), A.size() * sizeof(uint16_t));
+        if (rc) return rc;
+    }
     return GRHIP_OK;
 }
 
@@ -123,6 +139,38 @@ int XlatingCore::build(int device)
             rc = upload(d_vtab, V.data(), V.size() * sizeof(cf));
             if (rc) return rc;
         }
+    }
+    use_mfma = false;
+    if (real_proto && mfma_supported(decim, ntaps) && ntaps / decim >= 24) {
+        // pre-mix form on the matrix cores: x'[u] = x[u] e^{jw(u - off)}, real prototype taps
+        std::vector<float> pr(ntaps);
+        for (int i = 0; i < ntaps; ++i) pr[i] = proto[i].real();
+        rc = build_mfma_taps(pr.data(), ntaps, decim, d_mf_A, &mf_kexp);
+        if (rc) return rc;
+        const int KS = mf::ksteps_inst(decim, ntaps);
+        for (int off = 0; off < 2; ++off) {
+            std::vector<cf> W(mf::THREADS);
+            for (int t = 0; t < mf::THREADS; ++t) {
+                double ang = omega * (double)(2 * t - off);
+                W[t] = cf((float)cos(ang), (float)sin(ang));
+            }
+            rc = upload(d_mf_wlane[off], W.data(), W.size() * sizeof(cf));
+            if (rc) return rc;
+        }
+        std::vector<cf> S(mf::rounds(decim, KS)), V(mf::NTC + 2);
+        for (int i = 0; i < (int)S.size(); ++i) {
+            double ang = omega * (double)mf::ROUND * (double)i;
+            S[i] = cf((float)cos(ang), (float)sin(ang));
+        }
+        for (int j = 0; j < (int)V.size(); ++j) {
+            double ang = -omega * (double)j * (double)decim;
+            V[j] = cf((float)cos(ang), (float)sin(ang));
+        }
+        mf_wstep[0] = (float)cos(omega); mf_wstep[1] = (float)sin(omega);
+        rc = upload(d_mf_stab, S.data(), S.size() * sizeof(cf));
+        if (!rc) rc = upload(d_mf_vtab, V.data(), V.size() * sizeof(cf));
+        if (rc) return rc;
+        use_mfma = true;
     }
     use_ols = false;
     if (ntaps >= 48 && ntaps <= OLS_MAX_TAPS && (OLS_N - (ntaps - 1)) / decim >= 1) {
@@ -234,6 +282,8 @@ int XlatingCore::phase_before_pos(std::complex<float> *g)
 void XlatingCore::release()
 {
     d_taps_generic.release(); d_hp.release(); d_wtab.release(); d_stab.release(); d_vtab.release(); d_rot.release();
+    for (int i = 0; i < 2; ++i) { d_mf_A[i].release(); d_mf_wlane[i].release(); }
+    d_mf_stab.release(); d_mf_vtab.release(); mf_sched.release();
     scratch_y.release(); sched.release(); d_ols_tw.release(); d_ols_H.release(); d_hidec_taps.release();
     d_hidec_etab.release(); d_hidec_vtab.release();
 }
@@ -249,14 +299,34 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
     const float2 *gtab = nullptr;
     const bool demod = d_demod != nullptr;
     const bool batched = !(n_streams == 1 && n_lo == 0);
-    const bool direct = demod_is_direct(mode, demod, batched);
+    const bool mfma_now = mode_matrix(mode) && use_mfma && (n_streams == 1 || !(x_stride & 1));
+    const bool direct = mfma_now ? demod
+                                 : (demod && mode_fast(mode) && use_tiled && premix && (batched || !prefer_ols));
     int rc = GRHIP_OK;
     if (!direct) {          // the direct demodulator epilogue needs no rotator phases
         rc = ensure_rot(n_out, &gtab);
         if (rc) return rc;
     }
-    const bool ols_now = mode == GRHIP_MODE_FAST && (prefer_ols || (use_hidec && !use_tiled)) && !batched;
-    if (mode == GRHIP_MODE_FAST && use_tiled && !ols_now) {
+    if (mfma_now) {
+        FirMfmaArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = d_in; a.x_stride = x_stride; a.n_in = n_in; a.n_lo = n_lo; a.n_out = n_out; a.n_streams = n_streams;
+        a.off = (int)((((uintptr_t)d_in) >> 3) & 1);
+        a.A = d_mf_A[a.off].p; a.kexp = mf_kexp;
+        a.wlane = d_mf_wlane[a.off].as<float2>(); a.wstep = make_float2(mf_wstep[0], mf_wstep[1]);
+        a.stab = d_mf_stab.as<float>(); a.vtab = d_mf_vtab.as<float2>(); a.gtab = gtab;
+        a.y_out = d_y; a.d_out = d_demod; a.y_stride = out_stride; a.d_stride = out_stride;
+        a.gain = gain; a.y_prev = y_prev; a.y_last = y_last; a.atan_tab = atan_tab;
+        const uintptr_t o = demod ? (uintptr_t)d_demod : (uintptr_t)d_y;
+        a.vec_store = demod ? ((o & 7) == 0 && !(out_stride & 1)) : ((o & 15) == 0 && !(out_stride & 1));
+        a.sched = mf_sched.get();
+        rc = launch_fir_mfma(decim, ntaps, true, demod ? EPI_DEMOD : EPI_ROTATE, a, st);
+        if (rc) return rc;
+        pos += n_out;
+        return GRHIP_OK;
+    }
+    const bool ols_now = mode_fast(mode) && (prefer_ols || (use_hidec && !use_tiled)) && !batched;
+    if (mode_fast(mode) && use_tiled && !ols_now) {
         FirTiledArgs a;
         memset(&a, 0, sizeof(a));
         a.x = d_in; a.x_stride = x_stride; a.n_in = n_in; a.n_lo = n_lo;
@@ -367,6 +437,11 @@ struct grhip_fir_filter : HandleBase {
     // ... and the high-decimation direct kernel where a polyphase component has few taps (fir_kernels.hip)
     bool use_hidec = false;
     DevBuf d_hidec_taps;
+    // ... and the matrix-core engine for long real-tap filters on complex data (fir_mfma.hip)
+    bool use_mfma = false;
+    int mf_kexp = 0;
+    DevBuf d_mf_A[2];
+    SchedBuf mf_sched;
 
     int tw() const { return kind == FIR_CCC ? 2 : 1; }
     size_t in_item() const { return kind == FIR_FFF ? 4 : 8; }
@@ -392,6 +467,12 @@ struct grhip_fir_filter : HandleBase {
                 if (rc) return rc;
                 use_tiled = true;
             }
+        }
+        use_mfma = false;
+        if (kind == FIR_CCF && mfma_supported(decim, ntaps) && ntaps / decim >= 24) {
+            rc = build_mfma_taps(rev.data(), ntaps, decim, d_mf_A, &mf_kexp);
+            if (rc) return rc;
+            use_mfma = true;
         }
         use_ols = false;
         if (ntaps >= 48 && ntaps <= OLS_MAX_TAPS && (OLS_N - (ntaps - 1)) / decim >= 1) {
@@ -422,7 +503,18 @@ struct grhip_fir_filter : HandleBase {
     int run(const void *d_in, void *d_out, long long n, int dec, hipStream_t st)
     {
         if (n <= 0) return GRHIP_OK;
-        if (mode == GRHIP_MODE_FAST && use_tiled && !prefer_ols && dec == decim && (kind != FIR_FFF || n >= 2)) {
+        if (mode_matrix(mode) && use_mfma && dec == decim) {
+            FirMfmaArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = (const float2 *)d_in; a.n_in = (n - 1) * dec + ntaps; a.n_out = n; a.n_streams = 1;
+            a.off = (int)((((uintptr_t)d_in) >> 3) & 1);
+            a.A = d_mf_A[a.off].p; a.kexp = mf_kexp;
+            a.y_out = (float2 *)d_out;
+            a.vec_store = (((uintptr_t)d_out) & 15) == 0;
+            a.sched = mf_sched.get();
+            return launch_fir_mfma(dec, ntaps, false, EPI_NONE, a, st);
+        }
+        if (mode_fast(mode) && use_tiled && !prefer_ols && dec == decim && (kind != FIR_FFF || n >= 2)) {
             FirTiledArgs a;
             memset(&a, 0, sizeof(a));
             a.x = (const float2 *)d_in; a.n_in = (n - 1) * dec + ntaps;
@@ -439,10 +531,10 @@ struct grhip_fir_filter : HandleBase {
             return launch_fir_generic(kind, d_taps_rev.as<float>(), ntaps, (const float *)d_in + (n - 1) * dec,
                                       (float *)d_out + (n - 1), 1, dec, nullptr, st);
         }
-        if (mode == GRHIP_MODE_FAST && use_hidec && dec == decim)
+        if (mode_fast(mode) && use_hidec && dec == decim)
             return launch_fir_hidec(kind == FIR_CCC, d_hidec_taps.as<float>(), ntaps, dec, (const float2 *)d_in,
                                     (n - 1) * dec + ntaps, (float2 *)d_out, n, nullptr, st);
-        if (mode == GRHIP_MODE_FAST && use_ols && (prefer_ols || !use_tiled) && dec == decim) {
+        if (mode_fast(mode) && use_ols && (prefer_ols || !use_tiled) && dec == decim) {
             // y[n] = sum_k taps[k] x[nD + ntaps-1-k]: the ntaps-1 history items in front of d_in are the
             // engine's "previous call" samples, the rest is the stream
             if (kind == FIR_FFF) {
@@ -478,7 +570,7 @@ int grhip_fir_filter_create(grhip_fir_filter **h, const char *kind, int decimati
     f->kind = k; f->decim = decimation; f->mode = default_mode();
     int rc = f->init_device(device);
     if (!rc) rc = f->install(std::vector<float>(taps, taps + ntaps * f->tw()));
-    if (rc) { f->d_taps_rev.release(); f->d_hp.release(); f->sched.release(); f->d_ols_tw.release(); f->d_ols_H.release(); f->d_hidec_taps.release(); f->destroy_base(); delete f; return rc; }
+    if (rc) { f->d_taps_rev.release(); f->d_hp.release(); f->sched.release(); f->d_ols_tw.release(); f->d_ols_H.release(); f->d_hidec_taps.release(); f->d_mf_A[0].release(); f->d_mf_A[1].release(); f->mf_sched.release(); f->destroy_base(); delete f; return rc; }
     *h = f;
     return GRHIP_OK;
 }
@@ -488,6 +580,7 @@ void grhip_fir_filter_destroy(grhip_fir_filter *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     h->d_taps_rev.release(); h->d_hp.release(); h->sched.release(); h->d_ols_tw.release(); h->d_ols_H.release(); h->d_hidec_taps.release();
+    h->d_mf_A[0].release(); h->d_mf_A[1].release(); h->mf_sched.release();
     h->destroy_base();
     delete h;
 }
@@ -503,7 +596,7 @@ int grhip_fir_filter_set_taps(grhip_fir_filter *h, const float *taps, size_t nta
 
 int grhip_fir_filter_set_mode(grhip_fir_filter *h, int mode)
 {
-    if (!h || (mode != GRHIP_MODE_FAST && mode != GRHIP_MODE_GENERIC)) return fail(GRHIP_EINVAL, "bad mode");
+    if (!h || !mode_valid(mode)) return fail(GRHIP_EINVAL, "bad mode");
     h->mode = mode;
     return GRHIP_OK;
 }
@@ -677,7 +770,7 @@ int grhip_freq_xlating_fir_filter_ccc_set_taps(grhip_freq_xlating_fir_filter_ccc
 
 int grhip_freq_xlating_fir_filter_ccc_set_mode(grhip_freq_xlating_fir_filter_ccc *h, int mode)
 {
-    if (!h || (mode != GRHIP_MODE_FAST && mode != GRHIP_MODE_GENERIC)) return fail(GRHIP_EINVAL, "bad mode");
+    if (!h || !mode_valid(mode)) return fail(GRHIP_EINVAL, "bad mode");
     h->mode = mode;
     return GRHIP_OK;
 }
@@ -844,7 +937,7 @@ void grhip_xlating_demod_destroy(grhip_xlating_demod *h)
 
 int grhip_xlating_demod_set_mode(grhip_xlating_demod *h, int mode)
 {
-    if (!h || (mode != GRHIP_MODE_FAST && mode != GRHIP_MODE_GENERIC)) return fail(GRHIP_EINVAL, "bad mode");
+    if (!h || !mode_valid(mode)) return fail(GRHIP_EINVAL, "bad mode");
     h->mode = mode;
     return GRHIP_OK;
 }
@@ -904,14 +997,14 @@ int grhip_xlating_demod_run_captures_device(grhip_xlating_demod *h, int n_stream
     if (rc) return rc;
     const long long n_out = (long long)(n_samples / (size_t)h->core.decim);
     if (n_out <= 0) return GRHIP_OK;
-    if (!(h->mode == GRHIP_MODE_FAST && h->core.use_tiled))
-        return fail(GRHIP_EINVAL, "run_captures needs the tiled path (FAST mode, supported decimation)");
-    if (h->core.tab_start != 0 && !h->core.demod_is_direct(GRHIP_MODE_FAST, true, true))
+    if (!(mode_fast(h->mode) && (h->core.use_tiled || (mode_matrix(h->mode) && h->core.use_mfma))))
+        return fail(GRHIP_EINVAL, "run_captures needs a batched engine (FAST mode, supported decimation)");
+    if (h->core.tab_start != 0 && !h->core.demod_is_direct(h->mode, true, true))
         return fail(GRHIP_EINVAL, "handle has streamed past its cached rotator table; use a fresh handle");
     const long long hist = h->core.ntaps > 0 ? h->core.ntaps - 1 : 0;
     const long long keep = h->core.pos;
     h->core.pos = 0;                                  // every capture starts at rotator phase 1
-    rc = h->core.run(GRHIP_MODE_FAST, (const float2 *)d_in - hist, hist + (long long)n_samples, n_out, nullptr,
+    rc = h->core.run(h->mode, (const float2 *)d_in - hist, hist + (long long)n_samples, n_out, nullptr,
                      (float *)d_out, h->gain, nullptr, nullptr, h->tabs->atan_tab, h->pick(stream), n_streams,
                      (long long)in_stride_items, hist, (long long)out_stride_items);
     h->core.pos = keep;

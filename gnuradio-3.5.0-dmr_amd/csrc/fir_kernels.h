@@ -62,6 +62,36 @@ int tiled_load_span();              // samples covered by one round of 16-byte l
 int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiledArgs &a,
                      int n_streams, hipStream_t st);
 
+// ---- (B2) matrix-core engine (fir_mfma.hip): real taps, complex data, decimation 2 / 4, up to ~260 taps ----
+struct FirMfmaArgs {
+    const float2 *x;        // stream 0; item 0 = input[0] of output 0
+    long long x_stride;     // items between streams (even)
+    long long n_in;         // items at index >= n_in read as 0
+    long long n_lo;         // items at index <  n_lo read as 0 (never dereferenced)
+    long long n_out;        // outputs per stream
+    int n_streams;
+    int off;                // (address of x / 8) & 1: parity of the stream's 16-byte alignment
+    const void *A;          // mf::build_A() table for that parity
+    int kexp;               // taps were scaled by 2^kexp
+    const float2 *wlane;    // PREMIX: [256] e^{jw(2t - off)}
+    float2 wstep;           // PREMIX: e^{jw}
+    const float *stab;      // PREMIX: [rounds] e^{jw 512 i} (re, im)
+    const float2 *vtab;     // PREMIX: [NTC] e^{-jw j D}
+    const float2 *gtab;     // EPI_ROTATE: rotator phase per output of this call
+    float2 *y_out;          // EPI_NONE / EPI_ROTATE
+    long long y_stride;
+    float *d_out;           // EPI_DEMOD
+    long long d_stride;
+    float gain;
+    const float2 *y_prev;   // EPI_DEMOD: [n_streams] carry in (null: zeros)
+    float2 *y_last;         // EPI_DEMOD: [n_streams] carry out (null: none)
+    const float *atan_tab;
+    int vec_store;          // outputs may be stored two at a time (row base and stride aligned)
+    unsigned *sched;        // tile queue counters (as FirTiledArgs::sched), or null
+};
+bool mfma_supported(int decim, int ntaps);
+int launch_fir_mfma(int decim, int ntaps, bool premix, int epi, const FirMfmaArgs &a, hipStream_t st);
+
 // high-decimation direct form (FAST mode): c[k] multiplies x[n*decim + k] (complex interleaved if ctaps), given
 // as hidec_pad_taps() lays them out; x item 0 = input[0] of output 0, items >= n_in read as zero; optional rotator table
 bool hidec_supported(int decim, int ntaps);

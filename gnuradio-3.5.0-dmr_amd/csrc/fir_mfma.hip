@@ -1,0 +1,492 @@
+// fir_mfma.hip -- FAST-mode engine of the long decimating FIRs with REAL taps on complex data
+// (gr_fir_ccf, and gr_freq_xlating_fir_filter_ccc with a real prototype in its pre-mix form,
+// with the fused quadrature demodulator): the FIR as a banded-Toeplitz product on the matrix
+// cores.
+//
+// Why: at 256 taps the direct form is VALU-bound (28 flop/B against a ridge of
+// 19.7): fir_tiled.hip runs the vector pipes 84 % busy and still reaches only 0.35 of the HBM
+// roofline.  The contraction itself is dense -- 16 consecutive outputs of a decimating FIR are
+// a 16 x (15 D + T) band matrix of taps times a matrix of samples whose columns are
+// independent stream segments (mfma_tables.h) -- and v_mfma_f32_16x16x32_f16 retires it at
+// 16x the fp32 vector rate.  binary16 alone has 11 significant bits, so both operands are
+// split in two binary16 halves, x = xh + xl to ~22 bits (the taps on the host, the samples
+// while they are staged, after a per-tile power-of-two scaling that puts the tile's largest
+// sample at 2^14: the low halves stay normal numbers), and a product is three MFMAs
+// (Ah Xh + Ah Xl + Al Xh) accumulated in f32: 3/16 of the fp32 time at 80 % band occupancy.
+// Deviation from the f32 direct form ~3e-7 of sum|h||x| (tests: the same 1e-5 as before).
+// What is left on the vector pipes is staging (pre-mix, split: ~7 operations per sample) and
+// the demodulator; the kernel is bound by HBM.
+//
+//  * Persistent 256-lane workgroups, 2 per CU, tiles of NTC = 2000 computed outputs (1984
+//    new) handed out as in fir_tiled.hip (two static tiles, then a queue).
+//  * The tile is fetched with 16-byte raw buffer loads into registers one tile ahead (range
+//    check = history zeros and stream end), scaled, pre-mixed, split and written to four
+//    binary16 planes in LDS (re-hi, re-lo, im-hi, im-lo), sample u at byte 2u + 32 (u / Q),
+//    Q = 64 D: the skew puts the 8 segments of a wave on different LDS slots, so the operand
+//    reads (ds_read_b128, 8 consecutive samples of one segment per lane) are conflict-free.
+//  * Wave w owns 8 segments of 64 outputs (columns = segment x {re, im}).  It slides along
+//    them in chunks of 32 samples: chunk c is k-step c - 2b of block b (D = 4), so every
+//    chunk is read from LDS once and multiplied against up to 5 k-steps of A held in
+//    registers (80 VGPRs).
+//  * Epilogue per 16-output block through a wave-private LDS scratch (no barrier): the
+//    accumulator tile is written [segment][row][re,im] and read back as two consecutive
+//    complex outputs per lane; the demodulator's predecessor is the neighbouring lane's
+//    second output (DPP), the previous block's last output, or -- first output of a segment --
+//    the previous segment's last output, handled after the last block.  The first block of
+//    every wave is OVERLAP: it is computed only to hand its last output on, which makes the
+//    waves of a tile and the tiles of a stream independent.
+#include <cstdio>
+#include <cstdlib>
+
+#include "device_math.h"
+#include "fir_kernels.h"
+#include "grhip_internal.h"
+#include "mfma_tables.h"
+
+namespace grhip {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const float __attribute__((address_space(4))) *cfloat_cp;
+
+namespace {
+
+__host__ __device__ constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+
+constexpr int SCR_SEG = 36;                          // floats per segment of the epilogue scratch (32 + pad)
+constexpr int SCR_WAVE = mf::SEGS * SCR_SEG;         // floats per wave
+
+template <int D, int KS> struct Geo {
+    static constexpr int Q = mf::SEG_OUT * D;        // samples between segment starts
+    static constexpr int LOGQ = ilog2c(Q);
+    static constexpr int CB = mf::BLK * D / mf::CHUNK;   // chunks between block starts
+    static constexpr int NCH = mf::chunks_per_seg(D, KS);
+    static constexpr int SP = mf::tile_samples(D, KS);
+    static constexpr int NI = mf::rounds(D, KS);
+    static constexpr int PL = mf::plane_bytes(D, KS);
+    static constexpr int OFF_SCR = 4 * PL;
+    static constexpr int OFF_ATAN = OFF_SCR + mf::WAVES * SCR_WAVE * 4;
+    static constexpr int OFF_MISC = OFF_ATAN + 256 * 8;
+    static constexpr int LDS = OFF_MISC + 32;        // 4 wave maxima, the queue's hand-over slot
+    static_assert((1 << LOGQ) == Q, "segment stride must be a power of two");
+    static_assert(mf::ROUND % Q == 0, "a staging round must cover whole segment strides");
+};
+
+// max over the 64 lanes of a wave of a non-negative value (DPP, as wave_sum in fir_tiled.hip:
+// rows masked out of the row_bcast steps contribute 0)
+#define GRHIP_DPPF(v, ctrl, rmask, bc) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, (bc)))
+__device__ __forceinline__ float wave_max_nonneg(float x)
+{
+    x = __builtin_fmaxf(x, GRHIP_DPPF(x, 0xB1, 0xf, true));
+    x = __builtin_fmaxf(x, GRHIP_DPPF(x, 0x4E, 0xf, true));
+    x = __builtin_fmaxf(x, GRHIP_DPPF(x, 0x141, 0xf, true));
+    x = __builtin_fmaxf(x, GRHIP_DPPF(x, 0x140, 0xf, true));
+    x = __builtin_fmaxf(x, GRHIP_DPPF(x, 0x142, 0xa, false));
+    x = __builtin_fmaxf(x, GRHIP_DPPF(x, 0x143, 0xc, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
+// value of the lane `delta` places down the same row of 16 (DPP row_shr) / up (row_shl)
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+struct AtanPairs {
+    const f32x2 *p;
+    __device__ __forceinline__ f32x2 operator[](int k) const { return p[k]; }
+};
+
+}  // namespace
+
+template <int D, int KS, bool PREMIX, int EPI>
+__global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaArgs a)
+{
+    using G = Geo<D, KS>;
+    constexpr int NI = G::NI, PL = G::PL, LOGQ = G::LOGQ, NCH = G::NCH, CB = G::CB, SP = G::SP;
+    constexpr bool DEMOD = EPI == EPI_DEMOD;
+    constexpr bool ROT = EPI == EPI_ROTATE;
+    static_assert(!DEMOD || PREMIX, "the fused demodulator belongs to the pre-mix form");
+    static_assert(EPI == EPI_DEMOD || EPI == EPI_ROTATE || EPI == EPI_NONE, "epilogue");
+    constexpr int NTE = mf::NTE, BLK = mf::BLK, NBLK = mf::NBLK;
+
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    float *scr = reinterpret_cast<float *>(smem + G::OFF_SCR);
+    const AtanPairs s_atan{reinterpret_cast<const f32x2 *>(smem + G::OFF_ATAN)};
+    float *wmax = reinterpret_cast<float *>(smem + G::OFF_MISC);
+    unsigned *sched_slot = reinterpret_cast<unsigned *>(smem + G::OFF_MISC + 16);
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int tiles_per_stream = (int)((a.n_out + NTE - 1) / NTE);
+
+    // ---- launch constants ---------------------------------------------------------
+    // band matrix of the taps, both halves, every k-step: registers for the whole launch
+    h16x8 Ah[KS], Al[KS];
+    {
+        const h16x8 *Ag = reinterpret_cast<const h16x8 *>(a.A);
+#pragma unroll
+        for (int js = 0; js < KS; ++js) {
+            Ah[js] = Ag[(js * 2 + 0) * 64 + lane];
+            Al[js] = Ag[(js * 2 + 1) * 64 + lane];
+        }
+    }
+    // pre-mix phasors of the lane's two samples of round 0: e^{jw(2t - off)}, e^{jw(2t + 1 - off)}
+    f32x2 wl{1.f, 0.f}, wl1{1.f, 0.f};
+    if (PREMIX) {
+        const float2 v = a.wlane[t];
+        wl = f32x2{v.x, v.y};
+        wl1 = cmul_pk(wl, f32x2{a.wstep.x, a.wstep.y});
+    }
+    const cfloat_cp stab = (cfloat_cp)a.stab;
+    if (DEMOD) {
+        f32x2 *at = reinterpret_cast<f32x2 *>(smem + G::OFF_ATAN);
+        for (int i = t; i < 256; i += mf::THREADS) at[i] = f32x2{a.atan_tab[i], a.atan_tab[i + 1]};
+    }
+    // staging store: sample u = 2t + 512 i  ->  byte 2u + 32 (u >> LOGQ) of each plane
+    const int st_off = 4 * t + 32 * ((2 * t) >> LOGQ);
+    constexpr int ST_STEP = 2 * mf::ROUND + 32 * (mf::ROUND >> LOGQ);
+    // operand reads: lane = (column, k-group g); column = part * 8 + segment
+    const int col = lane & 15, part = col >> 3, sl = col & 7, g = lane >> 4;
+    const int rd_u = w * (mf::WAVE_NEW * D) + (sl << LOGQ) + 8 * g;       // sample of chunk 0
+    const int rd_plane = part * 2 * PL;
+    // epilogue scratch: written in the accumulator layout, read as 2 consecutive outputs per lane
+    float *scw = scr + w * SCR_WAVE;
+    const int sc_wr = sl * SCR_SEG + 8 * g + part;                      // + 2 i
+    const int rsl = lane >> 3, r8 = lane & 7;
+    const int sc_rd = rsl * SCR_SEG + 4 * r8;
+
+    f32x4 pf[NI];
+
+    // The stream is addressed through a raw buffer descriptor: lanes before the first real item
+    // (the history zeros of a fresh flowgraph) or past the end get zeros from the hardware
+    // range check.  The descriptor starts on a 16-byte boundary: when the first real item does
+    // not (lead = 1), it starts one item earlier -- same 16-byte granule, so the same
+    // allocation -- and that item is zeroed while staging (a 16-byte load at offset -8 would
+    // be out of range as a whole).
+    const int lead = a.off ^ (int)(a.n_lo & 1);
+    auto tile_geom = [&](int s, int b, __amdgpu_buffer_rsrc_t &rsrc, int &voff) {
+        const long long g0 = ((long long)b * NTE - BLK) * D - a.off - a.n_lo + lead;   // tile start relative to the descriptor
+        const float2 *x = a.x + (long long)s * a.x_stride + a.n_lo - lead;
+        const long long bytes = (a.n_in - a.n_lo + lead) * 8;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x), 0, (int)bytes, 0x00020000);
+        voff = (int)(g0 * 8) + 16 * t;              // negative = before the stream: out of range, zeros
+    };
+    // part < 0: all rounds; else the part-th quarter
+    auto fetch = [&](__amdgpu_buffer_rsrc_t rsrc, int voff, int part_) {
+        constexpr int PER = (NI + 3) / 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (part_ >= 0 && i / PER != part_) continue;
+            int vo = voff + i * (16 * mf::THREADS);
+            if ((i + 1) * mf::ROUND > SP && 2 * t + i * mf::ROUND >= SP) vo = 0x7ffff000;   // past the tile: no traffic
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
+            pf[i] = __builtin_bit_cast(f32x4, v);
+        }
+    };
+
+    const unsigned total_tiles = (unsigned)tiles_per_stream * (unsigned)a.n_streams;
+    const unsigned Gd = gridDim.x;
+    unsigned cur = blockIdx.x, nxt = cur + Gd;
+    auto decode = [&](unsigned id, int &s_, int &b_) {
+        b_ = (int)(id / (unsigned)a.n_streams);
+        s_ = (int)(id - (unsigned)b_ * (unsigned)a.n_streams);
+    };
+    int s = 0, bidx = 0;
+    decode(cur, s, bidx);
+    if (cur < total_tiles) {
+        __amdgpu_buffer_rsrc_t rsrc; int voff;
+        tile_geom(s, bidx, rsrc, voff);
+        fetch(rsrc, voff, -1);
+    }
+    unsigned nn = 0;
+    int voff_cur = 0;
+    if (lead) {
+        __amdgpu_buffer_rsrc_t rsrc;
+        tile_geom(s, bidx, rsrc, voff_cur);
+    }
+
+    while (cur < total_tiles) {
+        int s_nxt, b_nxt;
+        decode(nxt, s_nxt, b_nxt);
+
+        // ---- block floating point: the tile's largest |component| ---------------------
+        {
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(pf[i][0]), __builtin_fabsf(pf[i][1])));
+                m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(pf[i][2]), __builtin_fabsf(pf[i][3])));
+            }
+            m = wave_max_nonneg(m);
+            if (lane == 0) wmax[w] = m;
+            if (a.sched && t == 0) sched_slot[0] = nn;      // the queue's answer for the tile after next
+        }
+        __syncthreads();        // planes free (previous tile's operand reads done), maxima and slot visible
+        if (a.sched && cur != blockIdx.x) {
+            // (wave-uniform by construction; saying so keeps the stream's buffer descriptor in SGPRs)
+            nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)sched_slot[0]);
+            decode(nxt, s_nxt, b_nxt);
+        }
+        float scale, inv_scale;
+        {
+            const float mt = __builtin_fmaxf(__builtin_fmaxf(wmax[0], wmax[1]), __builtin_fmaxf(wmax[2], wmax[3]));
+            int k = 14 - __builtin_amdgcn_frexp_expf(mt);   // |x| e^{jw} components stay below 2^15
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            scale = __builtin_amdgcn_ldexpf(1.0f, k);
+            inv_scale = __builtin_amdgcn_ldexpf(1.0f, -k - a.kexp);
+        }
+
+        // ---- stage: registers -> (scale, pre-mix, split) -> LDS planes ---------------------
+        {
+            const f32x2 ws0 = wl * scale, ws1 = wl1 * scale;
+            unsigned char *dst = smem + st_off;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                f32x2 e0{pf[i][0], pf[i][1]}, e1{pf[i][2], pf[i][3]};
+                if (lead && voff_cur + i * (16 * mf::THREADS) == 0) e0 = f32x2{0.f, 0.f};     // the item in front of the stream
+                if (PREMIX) {
+                    const f32x2 S{stab[2 * i], stab[2 * i + 1]};
+                    e0 = cmul_pk(e0, cmul_pk(ws0, S));
+                    e1 = cmul_pk(e1, cmul_pk(ws1, S));
+                } else {
+                    e0 = e0 * scale;
+                    e1 = e1 * scale;
+                }
+                const f32x2 re{e0.x, e1.x}, im{e0.y, e1.y};
+                const h16x2 rh = __builtin_convertvector(re, h16x2), ih = __builtin_convertvector(im, h16x2);
+                const h16x2 rlo = __builtin_convertvector(re - __builtin_convertvector(rh, f32x2), h16x2);
+                const h16x2 ilo = __builtin_convertvector(im - __builtin_convertvector(ih, f32x2), h16x2);
+                if ((i + 1) * mf::ROUND <= SP || 2 * t + i * mf::ROUND < SP) {
+                    unsigned char *d = dst + i * ST_STEP;
+                    *reinterpret_cast<h16x2 *>(d) = rh;
+                    *reinterpret_cast<h16x2 *>(d + PL) = rlo;
+                    *reinterpret_cast<h16x2 *>(d + 2 * PL) = ih;
+                    *reinterpret_cast<h16x2 *>(d + 3 * PL) = ilo;
+                }
+            }
+        }
+        __syncthreads();
+
+        // next tile's HBM traffic flies under this tile's matrix phase and epilogue
+        __amdgpu_buffer_rsrc_t rsrc_n; int voff_n;
+        tile_geom(s_nxt, b_nxt, rsrc_n, voff_n);
+        if (nxt >= total_tiles) voff_n = 0x7ffff000 - NI * 16 * mf::THREADS;     // out of range: zeros, no traffic
+        if (a.sched && t == 0) nn = atomicAdd(a.sched, 1u) + 2u * Gd;          // arrives long before it is needed
+        else if (!a.sched) nn = nxt + Gd;
+
+        // ---- matrix phase --------------------------------------------------------------
+        f32x4 acc[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int u = rd_u + mf::CHUNK * c;
+            const unsigned char *src = smem + rd_plane + 2 * u + 32 * (u >> LOGQ);
+            const h16x8 Bh = *reinterpret_cast<const h16x8 *>(src);
+            const h16x8 Bl = *reinterpret_cast<const h16x8 *>(src + PL);
+            if ((c & 3) == 0 && c / 4 < 4) fetch(rsrc_n, voff_n, c / 4);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                const int j = c - CB * b;
+                if (j < 0 || j >= KS) continue;
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bl, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[j], Bh, acc[b], 0, 0, 0);
+            }
+        }
+        if (NCH <= 12) {        // short slides: the quarters not issued above
+#pragma unroll
+            for (int q = (NCH + 3) / 4; q < 4; ++q) fetch(rsrc_n, voff_n, q);
+        }
+
+        // ---- epilogue --------------------------------------------------------------------
+        // tile-local output index of this lane's first output of block b: jt + 16 b
+        const int jt = w * mf::WAVE_NEW + rsl * mf::SEG_OUT + 2 * r8;
+        const long long n_base = (long long)bidx * NTE - BLK + jt;        // stream index of that output (block 0)
+        float2 y_pend = make_float2(0.f, 0.f);      // first output of the segment, waits for its predecessor
+        float2 y1 = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) scw[sc_wr + 2 * i] = acc[b][i];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(scw + sc_rd);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const float2 y0 = make_float2(v[0], v[1]);
+            const float2 y1_prev_block = y1;
+            y1 = make_float2(v[2], v[3]);
+            const long long n = n_base + BLK * b;
+            if (DEMOD) {
+                // first block of the first wave of a stream's first tile: the predecessor of
+                // output 0 is the carry of the previous call (frame of the composite FIR
+                // output, fir_kernels.h), brought into this tile's frame and scale
+                if (b == 0 && bidx == 0 && w == 0 && lane == 7) {
+                    const float2 yp = a.y_prev ? a.y_prev[s] : make_float2(0.f, 0.f);
+                    const float2 vm = a.vtab[BLK - 1];
+                    float2 q = cmul_fma(yp, make_float2(vm.x, -vm.y));
+                    const float sc2 = __builtin_amdgcn_ldexpf(scale, a.kexp);
+                    y1 = make_float2(q.x * sc2, q.y * sc2);
+                }
+                // predecessor of y0: the lane before (same segment), or the previous block's last output
+                float2 prev;
+                prev.x = dpp_row<0x111>(y1.x);      // row_shr:1
+                prev.y = dpp_row<0x111>(y1.y);
+                if (b > 0) {
+                    const float cx = dpp_row<0x107>(y1_prev_block.x);   // row_shl:7: lane + 7
+                    const float cy = dpp_row<0x107>(y1_prev_block.y);
+                    if (r8 == 0) prev = make_float2(cx, cy);
+                } else {
+                    y_pend = y0;
+                }
+                const float d0 = quad_demod_fast(y0, prev, a.gain, s_atan);
+                const float d1 = quad_demod_fast(y1, y0, a.gain, s_atan);
+                float *__restrict__ o = a.d_out + (long long)s * a.d_stride;
+                const bool own = !(b == 0 && rsl == 0);                  // the wave's overlap block stores nothing
+                if (own && n >= 0) {
+                    if (b == 0 && r8 == 0) {
+                        if (n + 1 < a.n_out) o[n + 1] = d1;
+                    } else if (n + 1 < a.n_out) {
+                        if (a.vec_store) *reinterpret_cast<f32x2 *>(o + n) = f32x2{d0, d1};
+                        else { o[n] = d0; o[n + 1] = d1; }
+                    } else if (n < a.n_out) {
+                        o[n] = d0;
+                    }
+                    if (a.y_last) {
+                        const long long last = a.n_out - 1;
+                        if (last == n || last == n + 1) {
+                            const int jj = jt + BLK * b + (int)(last - n);
+                            const float2 yy = last == n ? y0 : y1;
+                            const float2 c2 = cmul_fma(yy, a.vtab[jj]);
+                            a.y_last[s] = make_float2(c2.x * inv_scale, c2.y * inv_scale);
+                        }
+                    }
+                }
+            } else {
+                float2 o0 = y0, o1 = y1;
+                const int jj = jt + BLK * b;
+                if (PREMIX) {
+                    const float4 vv = *reinterpret_cast<const float4 *>(a.vtab + jj);   // e^{-jw j D}, jj even
+                    o0 = cmul_fma(o0, make_float2(vv.x, vv.y));
+                    o1 = cmul_fma(o1, make_float2(vv.z, vv.w));
+                }
+                o0.x *= inv_scale; o0.y *= inv_scale; o1.x *= inv_scale; o1.y *= inv_scale;
+                const bool own = !(b == 0 && rsl == 0);
+                if (own && n >= 0 && n < a.n_out) {
+                    if (ROT) {
+                        o0 = cmul_ref(o0, a.gtab[n]);                   // gr_rotator: z = in * d_phase
+                        if (n + 1 < a.n_out) o1 = cmul_ref(o1, a.gtab[n + 1]);
+                    }
+                    float2 *__restrict__ y = a.y_out + (long long)s * a.y_stride;
+                    if (n + 1 < a.n_out) {
+                        if (a.vec_store) *reinterpret_cast<float4 *>(y + n) = make_float4(o0.x, o0.y, o1.x, o1.y);
+                        else { y[n] = o0; y[n + 1] = o1; }
+                    } else {
+                        y[n] = o0;
+                    }
+                }
+            }
+        }
+        if (DEMOD) {
+            // first output of every segment but the wave's first: predecessor = last output of the
+            // segment before, i.e. the second output of the lane before, after the last block
+            const float px = __shfl_up(y1.x, 1), py = __shfl_up(y1.y, 1);
+            const long long n = n_base;
+            if (r8 == 0 && rsl != 0 && n >= 0 && n < a.n_out) {
+                const float d = quad_demod_fast(y_pend, make_float2(px, py), a.gain, s_atan);
+                a.d_out[(long long)s * a.d_stride + n] = d;
+                if (a.y_last && n == a.n_out - 1) {
+                    const float2 c2 = cmul_fma(y_pend, a.vtab[jt]);
+                    a.y_last[s] = make_float2(c2.x * inv_scale, c2.y * inv_scale);
+                }
+            }
+        }
+
+        cur = nxt;
+        if (!a.sched) nxt = nn;
+        s = s_nxt; bidx = b_nxt;
+        voff_cur = voff_n;
+    }
+    // the last workgroup out re-arms the queue for the next launch
+    if (a.sched && t == 0) {
+        __threadfence();
+        if (atomicAdd(a.sched + 1, 1u) == Gd - 1) {
+            a.sched[0] = 0;
+            a.sched[1] = 0;
+            __threadfence();
+        }
+    }
+}
+
+static int g_mf_cus = 0;
+
+template <int D, int KS, bool PREMIX, int EPI>
+static int launch_mfma_inst(const FirMfmaArgs &a, hipStream_t st)
+{
+    using G = Geo<D, KS>;
+    auto kern = fir_mfma_kernel<D, KS, PREMIX, EPI>;
+    static bool configured = false;
+    if (!configured) {
+        GRHIP_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        configured = true;
+    }
+    if (g_mf_cus == 0) {
+        int dev = 0, n = 0;
+        GRHIP_HIP(hipGetDevice(&dev));
+        GRHIP_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        g_mf_cus = n > 0 ? n : 256;
+    }
+    const long long tiles = ((a.n_out + mf::NTE - 1) / mf::NTE) * a.n_streams;
+    int wgs = (160 * 1024) / (G::LDS + 256);
+    if (wgs > 2) wgs = 2;
+    if (wgs < 1) wgs = 1;
+    long long grid = (long long)wgs * g_mf_cus;
+    if (grid > tiles) grid = tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(mf::THREADS), G::LDS, st, a);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+template <int D, int KS>
+static int launch_mfma_dk(bool premix, int epi, const FirMfmaArgs &a, hipStream_t st)
+{
+    if (premix) {
+        if (epi == EPI_DEMOD) return launch_mfma_inst<D, KS, true, EPI_DEMOD>(a, st);
+        if (epi == EPI_ROTATE) return launch_mfma_inst<D, KS, true, EPI_ROTATE>(a, st);
+        return fail(GRHIP_EINVAL, "matrix FIR: the pre-mix form needs a rotate or demod epilogue");
+    }
+    if (epi != EPI_NONE) return fail(GRHIP_EINVAL, "matrix FIR: real taps without pre-mix have no rotator");
+    return launch_mfma_inst<D, KS, false, EPI_NONE>(a, st);
+}
+
+bool mfma_supported(int decim, int ntaps) { return mf::supported(decim, ntaps); }
+
+// alignment the kernel needs from a launch: 16-byte loads per lane pair
+bool mfma_launch_ok(const FirMfmaArgs &a)
+{
+    if ((a.x_stride & 1) && a.n_streams > 1) return false;
+    return true;
+}
+
+int launch_fir_mfma(int decim, int ntaps, bool premix, int epi, const FirMfmaArgs &a_in, hipStream_t st)
+{
+    if (a_in.n_out <= 0 || a_in.n_streams <= 0) return GRHIP_OK;
+    if (!mf::supported(decim, ntaps)) return fail(GRHIP_EINVAL, "matrix FIR: unsupported shape");
+    if (!mfma_launch_ok(a_in)) return fail(GRHIP_EINVAL, "matrix FIR: odd stream stride");
+    if ((a_in.n_in - a_in.n_lo) * 8 >= (1ll << 31) - (1ll << 20))
+        return fail(GRHIP_EINVAL, "matrix FIR: more than 2 GiB of input per stream in one call; call work() in pieces");
+    const int KS = mf::ksteps_inst(decim, ntaps);
+    switch (decim * 100 + KS) {
+    case 406: return launch_mfma_dk<4, 6>(premix, epi, a_in, st);
+    case 410: return launch_mfma_dk<4, 10>(premix, epi, a_in, st);
+    case 206: return launch_mfma_dk<2, 6>(premix, epi, a_in, st);
+    case 210: return launch_mfma_dk<2, 10>(premix, epi, a_in, st);
+    }
+    return fail(GRHIP_EINVAL, "matrix FIR: unsupported decimation %d", decim);
+}
+
+}  // namespace grhip

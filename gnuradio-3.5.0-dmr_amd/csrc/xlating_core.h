@@ -38,6 +38,12 @@ struct XlatingCore {
     int ols_L = 0, ols_fold = 0;
     DevBuf d_ols_tw, d_ols_H, d_hidec_taps, d_hidec_etab, d_hidec_vtab;
     bool hidec_premix = false;
+    // FAST mode, real prototype, decimation 2 / 4, up to ~260 taps: matrix-core engine (fir_mfma.hip)
+    bool use_mfma = false;
+    int mf_kexp = 0;
+    float mf_wstep[2] = {1.f, 0.f};
+    DevBuf d_mf_A[2], d_mf_wlane[2], d_mf_stab, d_mf_vtab;     // [alignment parity]
+    SchedBuf mf_sched;
     DevBuf scratch_y;
     SchedBuf sched;                             // tile queue of the tiled kernel (one launch at a time per handle)
 
@@ -79,7 +85,8 @@ struct XlatingCore {
     // launches -- several streams, or history supplied by range check -- always take the tiled kernel)
     bool demod_is_direct(int mode, bool demod, bool batched = false) const
     {
-        return demod && mode == GRHIP_MODE_FAST && use_tiled && premix && (batched || !prefer_ols);
+        if (demod && mode_matrix(mode) && use_mfma) return true;
+        return demod && mode_fast(mode) && use_tiled && premix && (batched || !prefer_ols);
     }
     // d_in item 0 = input[0] of output 0 (oldest history item); items with index
     // < n_lo or >= n_in read as zero.  n_streams > 1: stream s at d_in + s*x_stride,

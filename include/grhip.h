@@ -70,13 +70,19 @@ GRHIP_API const char *grhip_version(void);
 
 /* numeric mode of the FIR-type blocks (process-wide default, may be
  * overridden per handle):
- *   GRHIP_MODE_FAST    tiled kernels, FMA, own summation order
- *                      (within 1e-5 relative of the reference)
+ *   GRHIP_MODE_FAST    fastest engine for the shape, own summation order (within
+ *                      1e-5 relative of the reference): tiled vector-FMA kernels, the
+ *                      overlap-save engine, and -- long real-tap filters at decimation
+ *                      2 / 4 -- the matrix-core engine (split-binary16 MFMA, f32
+ *                      accumulation; csrc/fir_mfma.hip)
+ *   GRHIP_MODE_FAST_VALU  as FAST but never the matrix cores: f32 FMAs on the vector
+ *                      pipes only (the north-star's "no MFMA" form; ~2x slower at 256 taps)
  *   GRHIP_MODE_GENERIC summation order and unfused arithmetic of
  *                      gr_fir_XXX_generic (filter/gr_fir_XXX_generic.cc.t:30-79):
  *                      bit-exact against the generic reference path */
 #define GRHIP_MODE_FAST 0
 #define GRHIP_MODE_GENERIC 1
+#define GRHIP_MODE_FAST_VALU 2
 GRHIP_API int grhip_set_default_mode(int mode);
 GRHIP_API int grhip_get_default_mode(void);
 

@@ -1,0 +1,175 @@
+"""-m gpu parity tests of the matrix-core FIR engine (csrc/fir_mfma.hip) through the C ABI
+against the CPU oracle: the FAST-mode engine of long real-tap filters at decimation 2 / 4.
+Same tolerance as every FAST path: ||y - ref||inf <= 1e-5 ||ref||inf, and per element where
+|ref| is not tiny (filter/qa_gr_fir_ccf.cc:151-152 style)."""
+import numpy as np
+import pytest
+
+from conftest import demod_close, rel_err_max
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rand_c(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+
+
+def _per_element(got, ref, floor=0.1):
+    big = np.abs(ref) > floor * np.abs(ref).max()
+    return float((np.abs(got[big] - ref[big]) / np.abs(ref[big])).max())
+
+
+# shapes that dispatch to the engine: ntaps / decim >= 24, k-steps <= 10
+@pytest.mark.parametrize("ntaps,decim", [(256, 4), (255, 4), (259, 4), (96, 4), (131, 4), (133, 4), (64, 2), (130, 2),
+                                         (256, 2), (289, 2)])
+@pytest.mark.parametrize("n", [1, 15, 17, 1983, 1985, 5003, 40001])
+def test_fir_ccf_matrix_engine(gpu, po, ntaps, decim, n):
+    rng = np.random.default_rng(ntaps * 100 + decim * 10 + n % 7)
+    nin = n * decim + ntaps - 1
+    x = _rand_c(rng, nin)
+    taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+    ref = po.fir_ccf(taps, x, n, decim)
+    blk = gpu.fir_filter_ccf(decim, taps)
+    got = blk.work(n, x)
+    assert rel_err_max(got, ref) <= TOL
+    if n > 100:
+        assert _per_element(got, ref) <= TOL
+    # the vector-pipe form of FAST agrees too (and is a different engine)
+    blk.set_mode(gpu.MODE_FAST_VALU)
+    got_v = blk.work(n, x)
+    assert rel_err_max(got_v, ref) <= TOL
+    if n > 100:
+        assert not np.array_equal(got_v, got)
+
+
+@pytest.mark.parametrize("shift", [0, 1, 2, 3])
+def test_alignment_parity_and_device_entry(gpu, po, shift):
+    """work_device on a stream whose first item sits on an 8-byte (not 16-byte) boundary: the
+    band matrix is shifted by one sample instead of the loads"""
+    import torch
+    rng = np.random.default_rng(77 + shift)
+    ntaps, decim, n = 256, 4, 9001
+    nin = n * decim + ntaps - 1
+    x = _rand_c(rng, nin)
+    taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+    ref = po.fir_ccf(taps, x, n, decim)
+    dev = torch.device("cuda", 0)
+    d_x = torch.zeros((nin + 8, 2), dtype=torch.float32, device=dev)
+    d_x[shift:shift + nin] = torch.from_numpy(x.view(np.float32).reshape(-1, 2))
+    d_y = torch.zeros((n + 8, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    blk = gpu.fir_filter_ccf(decim, taps)
+    assert blk.work_device(n, d_x[shift:], d_y[shift:], st) == n
+    st.synchronize()
+    got = d_y[shift:shift + n].cpu().numpy().reshape(-1).view(np.complex64)
+    assert rel_err_max(got, ref) <= TOL and _per_element(got, ref) <= TOL
+    assert float(d_y[:shift].abs().sum()) == 0.0 and float(d_y[shift + n:].abs().sum()) == 0.0     # nothing outside
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e-12, 1.0, 3e7, 1e25])
+def test_block_floating_point_scaling(gpu, po, scale):
+    """the per-tile power-of-two scaling keeps the split exact at any signal level, and a
+    quiet stretch next to a loud one keeps the engine's error relative to the tile's peak"""
+    rng = np.random.default_rng(5)
+    ntaps, decim, n = 256, 4, 12000
+    nin = n * decim + ntaps - 1
+    x = (_rand_c(rng, nin) * np.float32(scale)).astype(np.complex64)
+    taps = (rng.uniform(-1, 1, ntaps) * 3e-3).astype(np.float32)
+    ref = po.fir_ccf(taps, x, n, decim)
+    got = gpu.fir_filter_ccf(decim, taps).work(n, x)
+    assert np.isfinite(got).all()
+    assert rel_err_max(got, ref) <= TOL and _per_element(got, ref) <= TOL
+
+
+def test_all_zero_and_impulse(gpu, po):
+    ntaps, decim, n = 256, 4, 6000
+    nin = n * decim + ntaps - 1
+    taps = np.arange(1, ntaps + 1, dtype=np.float32)
+    blk = gpu.fir_filter_ccf(decim, taps)
+    assert not blk.work(n, np.zeros(nin, np.complex64)).any()
+    x = np.zeros(nin, np.complex64)
+    x[10000] = 1 - 2j
+    got = blk.work(n, x)
+    ref = po.fir_ccf(taps, x, n, decim)
+    assert np.array_equal(got, ref)         # integers up to 256 times 1, 2: exact in two binary16 halves
+
+
+@pytest.mark.parametrize("ntaps,decim,real_proto", [(256, 4, True), (129, 4, True), (200, 2, True)])
+def test_xlating_rotate_epilogue(gpu, po, wl, ntaps, decim, real_proto):
+    rng = np.random.default_rng(ntaps + decim)
+    n = 7001
+    x = wl.fsk4_capture(n * decim, stream_id=9)
+    proto = wl.lowpass_taps(ntaps, 200e3, 10e6).astype(np.complex64)
+    xin = wl.with_history(x, ntaps - 1)
+    ref = po.Xlating(decim, proto, 1.25e6, 10e6).work(xin, n)
+    blk = gpu.freq_xlating_fir_filter_ccc(decim, proto, 1.25e6, 10e6)
+    got = blk.work(n, xin)
+    assert rel_err_max(got, ref) <= TOL
+    assert _per_element(got, ref) <= TOL
+    blk2 = gpu.freq_xlating_fir_filter_ccc(decim, proto, 1.25e6, 10e6)
+    blk2.set_mode(gpu.MODE_FAST_VALU)
+    assert rel_err_max(blk2.work(n, xin), ref) <= TOL
+    # chunked: the rotator table and the tile grid restart at every call
+    blk.reset()
+    assert rel_err_max(gpu.run_sync_block(blk, x, chunk=2500), ref) <= TOL
+
+
+def test_xlating_demod_chunked_and_mode_switches(gpu, po, wl):
+    """fused xlating -> demod in pieces: the one-sample carry crosses calls, engines and modes"""
+    c = wl.CFG2
+    n = 1 << 17
+    x = wl.fsk4_capture(n)
+    proto = wl.cfg2_proto_taps()
+    ref = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], x)
+    nout = n // c["decim"]
+    hist = len(proto) - 1
+    xin = wl.with_history(x, hist)
+    blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
+    pieces = [1, 15, 16, 17, 1984, 1985, 3000, 1, 7001]
+    modes = [gpu.MODE_FAST, gpu.MODE_FAST_VALU, gpu.MODE_FAST, gpu.MODE_GENERIC, gpu.MODE_FAST]
+    out = []
+    pos = 0
+    k = 0
+    while pos < nout:
+        m = min(pieces[k % len(pieces)], nout - pos)
+        blk.set_mode(modes[k % len(modes)])
+        out.append(blk.work(m, xin[pos * c["decim"]: pos * c["decim"] + m * c["decim"] + hist]))
+        pos += m
+        k += 1
+    got = np.concatenate(out)
+    ok, worst = demod_close(got, ref, gain=c["demod_gain"])
+    assert ok, worst
+
+
+def test_run_captures_matches_single_stream(gpu, po, wl):
+    """batched launch over S captures (grid walks (stream, tile) pairs, history zeros from the
+    range check) == S single-stream runs"""
+    import torch
+    c = wl.CFG2
+    S, n = 5, 50000
+    proto = wl.cfg2_proto_taps()
+    nout = n // c["decim"]
+    dev = torch.device("cuda", 0)
+    row = ((n + 63) // 64) * 64
+    orow = ((nout + 63) // 64) * 64
+    d_in = torch.zeros((S, row, 2), dtype=torch.float32, device=dev)
+    xs = [wl.fsk4_capture(n, stream_id=s) for s in range(S)]
+    for s in range(S):
+        d_in[s, :n] = torch.from_numpy(xs[s].view(np.float32).reshape(-1, 2))
+    d_out = torch.zeros((S, orow), dtype=torch.float32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
+    blk.run_captures_device(S, n, d_in, row, d_out, orow, st)
+    st.synchronize()
+    got = d_out.cpu().numpy()
+    for s in range(S):
+        ref = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], xs[s])
+        ok, worst = demod_close(got[s, :nout], ref, gain=c["demod_gain"])
+        assert ok, (s, worst)
+        assert not got[s, nout:].any()
+    # twice in a row on the same handle (the tile queue re-arms itself)
+    d_out.zero_()
+    blk.run_captures_device(S, n, d_in, row, d_out, orow, st)
+    st.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), got)
