@@ -97,6 +97,17 @@ __device__ __forceinline__ float dpp_row(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
+// low halves of a split pair: (binary16)(x - (float)hi), one mixed-precision FMA per element
+// (x * 1.0 - hi with hi read as binary16, result rounded to binary16 into one half of the register)
+__device__ __forceinline__ h16x2 split_lo(f32x2 x, h16x2 hi)
+{
+    unsigned lo;
+    const unsigned h = __builtin_bit_cast(unsigned, hi);
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x.x), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x.y), "v"(h));
+    return __builtin_bit_cast(h16x2, lo);
+}
+
 struct AtanPairs {
     const f32x2 *p;
     __device__ __forceinline__ f32x2 operator[](int k) const { return p[k]; }
@@ -203,7 +214,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         tile_geom(s, bidx, rsrc, voff);
         fetch(rsrc, voff, -1);
     }
-    unsigned nn = 0;
+    unsigned nn_q = 0;          // the queue's answer: valid in lane 0 of the workgroup only
     int voff_cur = 0;
     if (lead) {
         __amdgpu_buffer_rsrc_t rsrc;
@@ -212,26 +223,25 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
 
     while (cur < total_tiles) {
         int s_nxt, b_nxt;
-        decode(nxt, s_nxt, b_nxt);
 
         // ---- block floating point: the tile's largest |component| ---------------------
         {
             float m = 0.f;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(pf[i][0]), __builtin_fabsf(pf[i][1])));
-                m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(pf[i][2]), __builtin_fabsf(pf[i][3])));
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(pf[i][0]), "v"(pf[i][1]));
+                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(pf[i][2]), "v"(pf[i][3]));
             }
             m = wave_max_nonneg(m);
             if (lane == 0) wmax[w] = m;
-            if (a.sched && t == 0) sched_slot[0] = nn;      // the queue's answer for the tile after next
+            if (a.sched && t == 0) sched_slot[0] = nn_q;    // the queue's answer for the tile after next
         }
         __syncthreads();        // planes free (previous tile's operand reads done), maxima and slot visible
-        if (a.sched && cur != blockIdx.x) {
-            // (wave-uniform by construction; saying so keeps the stream's buffer descriptor in SGPRs)
-            nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)sched_slot[0]);
-            decode(nxt, s_nxt, b_nxt);
-        }
+        if (a.sched && cur != blockIdx.x) nxt = sched_slot[0];
+        // (wave-uniform by construction; saying so keeps the stream's buffer descriptor in SGPRs --
+        // otherwise every load is wrapped in a waterfall loop)
+        nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
+        decode(nxt, s_nxt, b_nxt);
         float scale, inv_scale;
         {
             const float mt = __builtin_fmaxf(__builtin_fmaxf(wmax[0], wmax[1]), __builtin_fmaxf(wmax[2], wmax[3]));
@@ -259,8 +269,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                 }
                 const f32x2 re{e0.x, e1.x}, im{e0.y, e1.y};
                 const h16x2 rh = __builtin_convertvector(re, h16x2), ih = __builtin_convertvector(im, h16x2);
-                const h16x2 rlo = __builtin_convertvector(re - __builtin_convertvector(rh, f32x2), h16x2);
-                const h16x2 ilo = __builtin_convertvector(im - __builtin_convertvector(ih, f32x2), h16x2);
+                const h16x2 rlo = split_lo(re, rh), ilo = split_lo(im, ih);
                 if ((i + 1) * mf::ROUND <= SP || 2 * t + i * mf::ROUND < SP) {
                     unsigned char *d = dst + i * ST_STEP;
                     *reinterpret_cast<h16x2 *>(d) = rh;
@@ -276,28 +285,39 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         __amdgpu_buffer_rsrc_t rsrc_n; int voff_n;
         tile_geom(s_nxt, b_nxt, rsrc_n, voff_n);
         if (nxt >= total_tiles) voff_n = 0x7ffff000 - NI * 16 * mf::THREADS;     // out of range: zeros, no traffic
-        if (a.sched && t == 0) nn = atomicAdd(a.sched, 1u) + 2u * Gd;          // arrives long before it is needed
-        else if (!a.sched) nn = nxt + Gd;
+        if (a.sched && t == 0) nn_q = atomicAdd(a.sched, 1u) + 2u * Gd;        // arrives long before it is needed
 
         // ---- matrix phase --------------------------------------------------------------
         f32x4 acc[NBLK];
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // operand chunks are read one chunk ahead of their use (an LDS round trip is ~100 cycles:
+        // read at its use, every chunk would stall the wave's matrix pipe for that long)
+        auto chunk_ptr = [&](int c) {
+            const int u = rd_u + mf::CHUNK * c;
+            return smem + rd_plane + 2 * u + 32 * (u >> LOGQ);
+        };
+        h16x8 Bh_n = *reinterpret_cast<const h16x8 *>(chunk_ptr(0));
+        h16x8 Bl_n = *reinterpret_cast<const h16x8 *>(chunk_ptr(0) + PL);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int u = rd_u + mf::CHUNK * c;
-            const unsigned char *src = smem + rd_plane + 2 * u + 32 * (u >> LOGQ);
-            const h16x8 Bh = *reinterpret_cast<const h16x8 *>(src);
-            const h16x8 Bl = *reinterpret_cast<const h16x8 *>(src + PL);
+            const h16x8 Bh = Bh_n, Bl = Bl_n;
+            if (c + 1 < NCH) {
+                const unsigned char *src = chunk_ptr(c + 1);
+                Bh_n = *reinterpret_cast<const h16x8 *>(src);
+                Bl_n = *reinterpret_cast<const h16x8 *>(src + PL);
+            }
             if ((c & 3) == 0 && c / 4 < 4) fetch(rsrc_n, voff_n, c / 4);
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b) {
-                const int j = c - CB * b;
-                if (j < 0 || j >= KS) continue;
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bl, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[j], Bh, acc[b], 0, 0, 0);
+            for (int p = 0; p < 3; ++p) {        // the three products, every live block in turn: independent accumulators back to back
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) {
+                    const int j = c - CB * b;
+                    if (j < 0 || j >= KS) continue;
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 2 ? Al[j] : Ah[j], p == 1 ? Bl : Bh, acc[b], 0, 0, 0);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);      // keep the read-ahead where it is written
         }
         if (NCH <= 12) {        // short slides: the quarters not issued above
 #pragma unroll
@@ -407,7 +427,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         }
 
         cur = nxt;
-        if (!a.sched) nxt = nn;
+        if (!a.sched) nxt = nxt + Gd;
         s = s_nxt; bidx = b_nxt;
         voff_cur = voff_n;
     }
