@@ -317,6 +317,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         a.stab = d_mf_stab.as<float>(); a.vtab = d_mf_vtab.as<float2>(); a.gtab = gtab;
         a.y_out = d_y; a.d_out = d_demod; a.y_stride = out_stride; a.d_stride = out_stride;
         a.gain = gain; a.y_prev = y_prev; a.y_last = y_last; a.atan_tab = atan_tab;
+        a.ctaps = d_taps_generic.as<float2>(); a.T = ntaps;
         const uintptr_t o = demod ? (uintptr_t)d_demod : (uintptr_t)d_y;
         a.vec_store = demod ? ((o & 7) == 0 && !(out_stride & 1)) : ((o & 15) == 0 && !(out_stride & 1));
         a.sched = mf_sched.get();

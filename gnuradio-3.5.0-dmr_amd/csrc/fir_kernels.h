@@ -85,8 +85,10 @@ struct FirMfmaArgs {
     float gain;
     const float2 *y_prev;   // EPI_DEMOD: [n_streams] carry in (null: zeros)
     float2 *y_last;         // EPI_DEMOD: [n_streams] carry out (null: none)
+    const float2 *ctaps;    // EPI_DEMOD with y_last: composite taps c[i] (multiplying x[nD + i]), T of them
+    int T;
     const float *atan_tab;
-    int vec_store;          // outputs may be stored two at a time (row base and stride aligned)
+    int vec_store;          // (unused: outputs go through buffer stores, dword alignment suffices)
     unsigned *sched;        // tile queue counters (as FirTiledArgs::sched), or null
 };
 bool mfma_supported(int decim, int ntaps);

@@ -50,6 +50,7 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef const float __attribute__((address_space(4))) *cfloat_cp;
 
 namespace {
@@ -90,6 +91,17 @@ __device__ __forceinline__ float wave_max_nonneg(float x)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
+__device__ __forceinline__ float wave_sum_f(float x)
+{
+    x += GRHIP_DPPF(x, 0xB1, 0xf, true);
+    x += GRHIP_DPPF(x, 0x4E, 0xf, true);
+    x += GRHIP_DPPF(x, 0x141, 0xf, true);
+    x += GRHIP_DPPF(x, 0x140, 0xf, true);
+    x += GRHIP_DPPF(x, 0x142, 0xa, false);
+    x += GRHIP_DPPF(x, 0x143, 0xc, false);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 // value of the lane `delta` places down the same row of 16 (DPP row_shr) / up (row_shl)
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v)
@@ -108,6 +120,25 @@ __device__ __forceinline__ h16x2 split_lo(f32x2 x, h16x2 hi)
     return __builtin_bit_cast(h16x2, lo);
 }
 
+// Diagnostic build only (-DGRHIP_STAMP, `make stamp`): per-wave time shares of the phases of a
+// tile (100 MHz real-time counter), written to a buffer of their own (never to an output).
+#ifdef GRHIP_STAMP
+__device__ unsigned long long *g_mf_stamp_buf = nullptr;
+__device__ __forceinline__ unsigned long long mf_stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define MF_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = mf_stamp_now(), st_begin = st_last
+#define MF_STAMP(k) do { unsigned long long n__ = mf_stamp_now(); st_acc[k] += n__ - st_last; st_last = n__; } while (0)
+#else
+#define MF_STAMP_DECL
+#define MF_STAMP(k)
+#endif
+
 struct AtanPairs {
     const f32x2 *p;
     __device__ __forceinline__ f32x2 operator[](int k) const { return p[k]; }
@@ -119,7 +150,7 @@ template <int D, int KS, bool PREMIX, int EPI>
 __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaArgs a)
 {
     using G = Geo<D, KS>;
-    constexpr int NI = G::NI, PL = G::PL, LOGQ = G::LOGQ, NCH = G::NCH, CB = G::CB, SP = G::SP;
+    constexpr int NI = G::NI, PL = G::PL, LOGQ = G::LOGQ, CB = G::CB, SP = G::SP;
     constexpr bool DEMOD = EPI == EPI_DEMOD;
     constexpr bool ROT = EPI == EPI_ROTATE;
     static_assert(!DEMOD || PREMIX, "the fused demodulator belongs to the pre-mix form");
@@ -221,8 +252,10 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         tile_geom(s, bidx, rsrc, voff_cur);
     }
 
+    MF_STAMP_DECL;
     while (cur < total_tiles) {
         int s_nxt, b_nxt;
+        MF_STAMP(7);
 
         // ---- block floating point: the tile's largest |component| ---------------------
         {
@@ -236,7 +269,9 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
             if (lane == 0) wmax[w] = m;
             if (a.sched && t == 0) sched_slot[0] = nn_q;    // the queue's answer for the tile after next
         }
+        MF_STAMP(0);
         __syncthreads();        // planes free (previous tile's operand reads done), maxima and slot visible
+        MF_STAMP(1);
         if (a.sched && cur != blockIdx.x) nxt = sched_slot[0];
         // (wave-uniform by construction; saying so keeps the stream's buffer descriptor in SGPRs --
         // otherwise every load is wrapped in a waterfall loop)
@@ -252,13 +287,18 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         }
 
         // ---- stage: registers -> (scale, pre-mix, split) -> LDS planes ---------------------
+        if (lead && bidx == 0) {
+            // the item in front of a stream that does not start on a 16-byte boundary reads as zero
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (voff_cur + i * (16 * mf::THREADS) == 0) { pf[i][0] = 0.f; pf[i][1] = 0.f; }
+        }
         {
             const f32x2 ws0 = wl * scale, ws1 = wl1 * scale;
             unsigned char *dst = smem + st_off;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 f32x2 e0{pf[i][0], pf[i][1]}, e1{pf[i][2], pf[i][3]};
-                if (lead && voff_cur + i * (16 * mf::THREADS) == 0) e0 = f32x2{0.f, 0.f};     // the item in front of the stream
                 if (PREMIX) {
                     const f32x2 S{stab[2 * i], stab[2 * i + 1]};
                     e0 = cmul_pk(e0, cmul_pk(ws0, S));
@@ -279,7 +319,19 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                 }
             }
         }
+        // the carry of the previous call, for the stream's first tile (frame of the composite FIR
+        // output, fir_kernels.h), brought into this tile's frame and scale
+        float2 ypf = make_float2(0.f, 0.f);
+        if (DEMOD && bidx == 0 && a.y_prev) {
+            const float2 yp = a.y_prev[s];
+            const float2 vm = a.vtab[BLK - 1];
+            const float2 q = cmul_fma(yp, make_float2(vm.x, -vm.y));
+            const float sc2 = __builtin_amdgcn_ldexpf(scale, a.kexp);
+            ypf = make_float2(q.x * sc2, q.y * sc2);
+        }
+        MF_STAMP(2);
         __syncthreads();
+        MF_STAMP(3);
 
         // next tile's HBM traffic flies under this tile's matrix phase and epilogue
         __amdgpu_buffer_rsrc_t rsrc_n; int voff_n;
@@ -287,70 +339,41 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         if (nxt >= total_tiles) voff_n = 0x7ffff000 - NI * 16 * mf::THREADS;     // out of range: zeros, no traffic
         if (a.sched && t == 0) nn_q = atomicAdd(a.sched, 1u) + 2u * Gd;        // arrives long before it is needed
 
-        // ---- matrix phase --------------------------------------------------------------
-        f32x4 acc[NBLK];
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // operand chunks are read one chunk ahead of their use (an LDS round trip is ~100 cycles:
-        // read at its use, every chunk would stall the wave's matrix pipe for that long)
-        auto chunk_ptr = [&](int c) {
-            const int u = rd_u + mf::CHUNK * c;
-            return smem + rd_plane + 2 * u + 32 * (u >> LOGQ);
-        };
-        h16x8 Bh_n = *reinterpret_cast<const h16x8 *>(chunk_ptr(0));
-        h16x8 Bl_n = *reinterpret_cast<const h16x8 *>(chunk_ptr(0) + PL);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const h16x8 Bh = Bh_n, Bl = Bl_n;
-            if (c + 1 < NCH) {
-                const unsigned char *src = chunk_ptr(c + 1);
-                Bh_n = *reinterpret_cast<const h16x8 *>(src);
-                Bl_n = *reinterpret_cast<const h16x8 *>(src + PL);
-            }
-            if ((c & 3) == 0 && c / 4 < 4) fetch(rsrc_n, voff_n, c / 4);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {        // the three products, every live block in turn: independent accumulators back to back
-#pragma unroll
-                for (int b = 0; b < NBLK; ++b) {
-                    const int j = c - CB * b;
-                    if (j < 0 || j >= KS) continue;
-                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 2 ? Al[j] : Ah[j], p == 1 ? Bl : Bh, acc[b], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);      // keep the read-ahead where it is written
+        // output of this tile's stream, through a buffer descriptor: a store whose offset is out of
+        // range (past the end of the stream; or made so for the lanes that own no output) is dropped
+        // by the hardware, so the epilogue has no branches and can be interleaved with the MFMAs
+        constexpr int OOB = 0x7ffffff0;
+        __amdgpu_buffer_rsrc_t orsrc, grsrc;
+        if (DEMOD) {
+            orsrc = __builtin_amdgcn_make_buffer_rsrc(a.d_out + (long long)s * a.d_stride, 0, (int)(a.n_out * 4), 0x00020000);
+        } else {
+            orsrc = __builtin_amdgcn_make_buffer_rsrc(a.y_out + (long long)s * a.y_stride, 0, (int)(a.n_out * 8), 0x00020000);
+            if (ROT) grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.gtab), 0, (int)(a.n_out * 8), 0x00020000);
         }
-        if (NCH <= 12) {        // short slides: the quarters not issued above
-#pragma unroll
-            for (int q = (NCH + 3) / 4; q < 4; ++q) fetch(rsrc_n, voff_n, q);
-        }
-
-        // ---- epilogue --------------------------------------------------------------------
         // tile-local output index of this lane's first output of block b: jt + 16 b
         const int jt = w * mf::WAVE_NEW + rsl * mf::SEG_OUT + 2 * r8;
-        const long long n_base = (long long)bidx * NTE - BLK + jt;        // stream index of that output (block 0)
+        const int n_base = bidx * NTE - BLK + jt;          // stream index of that output (block 0); < 2^28
+        const bool first_of_stream = bidx == 0 && t == 7;   // lane (segment 0, rows 14/15) of wave 0
         float2 y_pend = make_float2(0.f, 0.f);      // first output of the segment, waits for its predecessor
+        float d1_pend = 0.f;
         float2 y1 = make_float2(0.f, 0.f);
+
+        // one 16-output block: accumulator tile -> scratch -> two consecutive outputs per lane -> demodulator / store
+        auto epilogue = [&](int b, const f32x4 &accb) {
 #pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) scw[sc_wr + 2 * i] = acc[b][i];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int i = 0; i < 4; ++i) scw[sc_wr + 2 * i] = accb[i];
+            asm volatile("" ::: "memory");          // (LDS executes a wave's operations in order; this orders the compiler)
             const f32x4 v = *reinterpret_cast<const f32x4 *>(scw + sc_rd);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
             const float2 y0 = make_float2(v[0], v[1]);
             const float2 y1_prev_block = y1;
             y1 = make_float2(v[2], v[3]);
-            const long long n = n_base + BLK * b;
+            const int n = n_base + BLK * b;
+            const bool own = !(b == 0 && rsl == 0) && n >= 0;       // the wave's overlap block stores nothing
             if (DEMOD) {
-                // first block of the first wave of a stream's first tile: the predecessor of
-                // output 0 is the carry of the previous call (frame of the composite FIR
-                // output, fir_kernels.h), brought into this tile's frame and scale
-                if (b == 0 && bidx == 0 && w == 0 && lane == 7) {
-                    const float2 yp = a.y_prev ? a.y_prev[s] : make_float2(0.f, 0.f);
-                    const float2 vm = a.vtab[BLK - 1];
-                    float2 q = cmul_fma(yp, make_float2(vm.x, -vm.y));
-                    const float sc2 = __builtin_amdgcn_ldexpf(scale, a.kexp);
-                    y1 = make_float2(q.x * sc2, q.y * sc2);
+                if (b == 0) {
+                    y1.x = first_of_stream ? ypf.x : y1.x;
+                    y1.y = first_of_stream ? ypf.y : y1.y;
                 }
                 // predecessor of y0: the lane before (same segment), or the previous block's last output
                 float2 prev;
@@ -359,73 +382,112 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                 if (b > 0) {
                     const float cx = dpp_row<0x107>(y1_prev_block.x);   // row_shl:7: lane + 7
                     const float cy = dpp_row<0x107>(y1_prev_block.y);
-                    if (r8 == 0) prev = make_float2(cx, cy);
+                    prev.x = r8 == 0 ? cx : prev.x;
+                    prev.y = r8 == 0 ? cy : prev.y;
                 } else {
                     y_pend = y0;
                 }
                 const float d0 = quad_demod_fast(y0, prev, a.gain, s_atan);
                 const float d1 = quad_demod_fast(y1, y0, a.gain, s_atan);
-                float *__restrict__ o = a.d_out + (long long)s * a.d_stride;
-                const bool own = !(b == 0 && rsl == 0);                  // the wave's overlap block stores nothing
-                if (own && n >= 0) {
-                    if (b == 0 && r8 == 0) {
-                        if (n + 1 < a.n_out) o[n + 1] = d1;
-                    } else if (n + 1 < a.n_out) {
-                        if (a.vec_store) *reinterpret_cast<f32x2 *>(o + n) = f32x2{d0, d1};
-                        else { o[n] = d0; o[n + 1] = d1; }
-                    } else if (n < a.n_out) {
-                        o[n] = d0;
-                    }
-                    if (a.y_last) {
-                        const long long last = a.n_out - 1;
-                        if (last == n || last == n + 1) {
-                            const int jj = jt + BLK * b + (int)(last - n);
-                            const float2 yy = last == n ? y0 : y1;
-                            const float2 c2 = cmul_fma(yy, a.vtab[jj]);
-                            a.y_last[s] = make_float2(c2.x * inv_scale, c2.y * inv_scale);
-                        }
-                    }
-                }
+                if (b == 0) d1_pend = d1;
+                const bool st_ok = own && !(b == 0 && r8 == 0);     // (a segment's first pair waits for its predecessor)
+                const f32x2 dd{d0, d1};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, dd), orsrc, st_ok ? 4 * n : OOB, 0, 0);
             } else {
                 float2 o0 = y0, o1 = y1;
-                const int jj = jt + BLK * b;
                 if (PREMIX) {
-                    const float4 vv = *reinterpret_cast<const float4 *>(a.vtab + jj);   // e^{-jw j D}, jj even
+                    const float4 vv = *reinterpret_cast<const float4 *>(a.vtab + jt + BLK * b);   // e^{-jw j D}
                     o0 = cmul_fma(o0, make_float2(vv.x, vv.y));
                     o1 = cmul_fma(o1, make_float2(vv.z, vv.w));
                 }
                 o0.x *= inv_scale; o0.y *= inv_scale; o1.x *= inv_scale; o1.y *= inv_scale;
-                const bool own = !(b == 0 && rsl == 0);
-                if (own && n >= 0 && n < a.n_out) {
-                    if (ROT) {
-                        o0 = cmul_ref(o0, a.gtab[n]);                   // gr_rotator: z = in * d_phase
-                        if (n + 1 < a.n_out) o1 = cmul_ref(o1, a.gtab[n + 1]);
-                    }
-                    float2 *__restrict__ y = a.y_out + (long long)s * a.y_stride;
-                    if (n + 1 < a.n_out) {
-                        if (a.vec_store) *reinterpret_cast<float4 *>(y + n) = make_float4(o0.x, o0.y, o1.x, o1.y);
-                        else { y[n] = o0; y[n + 1] = o1; }
-                    } else {
-                        y[n] = o0;
-                    }
+                if (ROT) {
+                    const u32x4 gv = __builtin_amdgcn_raw_buffer_load_b128(grsrc, own ? 8 * n : OOB, 0, 0);
+                    const f32x4 gq = __builtin_bit_cast(f32x4, gv);
+                    o0 = cmul_ref(o0, make_float2(gq[0], gq[1]));                   // gr_rotator: z = in * d_phase
+                    o1 = cmul_ref(o1, make_float2(gq[2], gq[3]));
                 }
+                // Two 8-byte stores, not one of 16: a store of more than 64 bits reads its data registers
+                // some time after it issues, and an MFMA issued behind it may already have rewritten them
+                // (measured: the compiler's wait states cover a vector-ALU writer only; one block in
+                // thirty came out with a stale real part).  Stores of up to 64 bits read at issue.
+                const f32x2 oa{o0.x, o0.y}, ob{o1.x, o1.y};
+                const int so = own ? 8 * n : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oa), orsrc, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), orsrc, so + 8, 0, 0);
+            }
+        };
+
+        // ---- matrix phase, block by block (30 MFMAs each) ----
+        // Operand chunks are read one chunk ahead of their use (an LDS round trip is ~100 cycles).
+        auto chunk_ptr = [&](int c) {
+            const int u = rd_u + mf::CHUNK * c;
+            return smem + rd_plane + 2 * u + 32 * (u >> LOGQ);
+        };
+        f32x4 acc[NBLK];
+        h16x8 Bh_n = *reinterpret_cast<const h16x8 *>(chunk_ptr(0));
+        h16x8 Bl_n = *reinterpret_cast<const h16x8 *>(chunk_ptr(0) + PL);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const h16x8 Bh = Bh_n, Bl = Bl_n;
+                const int cn = j + 1 < KS ? CB * b + j + 1 : CB * (b + 1);       // next chunk: this block's, or the next block's first
+                if (j + 1 < KS || b + 1 < NBLK) {
+                    const unsigned char *src = chunk_ptr(cn);
+                    Bh_n = *reinterpret_cast<const h16x8 *>(src);
+                    Bl_n = *reinterpret_cast<const h16x8 *>(src + PL);
+                }
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bl, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[j], Bh, acc[b], 0, 0, 0);
+                if (j == 1) fetch(rsrc_n, voff_n, b);       // a quarter of the next tile's loads per block
             }
         }
+        MF_STAMP(4);
+        // The epilogues run BEHIND the matrix phase, fenced off from it.  Letting hipcc 7.2 interleave
+        // them with the MFMAs of the following block (it does so eagerly: the code is branch-free) bought
+        // nothing (1.26 ms either way, same box) and, in the rotate epilogue, gave one 16-output block in
+        // thirty a stale real part (bit-reproducible per binary; gone with this fence, with a fence in
+        // front of the scratch stores only, and with 16 s_nop behind the output store).  Two suspects are
+        // ruled out by micro-tests kept in tools/dbg/: a vector write to an MFMA source register right
+        // behind the MFMA (mfma_war.hip: harmless), and too few wait states between the MFMA and the LDS
+        // store of its result (mfma_lds_raw*.hip: 6 suffice, alone or beside an MFMA-issuing partner wave;
+        // hipcc pads 8).  Unresolved; the fence costs nothing.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) epilogue(b, acc[b]);
         if (DEMOD) {
             // first output of every segment but the wave's first: predecessor = last output of the
             // segment before, i.e. the second output of the lane before, after the last block
             const float px = __shfl_up(y1.x, 1), py = __shfl_up(y1.y, 1);
-            const long long n = n_base;
-            if (r8 == 0 && rsl != 0 && n >= 0 && n < a.n_out) {
-                const float d = quad_demod_fast(y_pend, make_float2(px, py), a.gain, s_atan);
-                a.d_out[(long long)s * a.d_stride + n] = d;
-                if (a.y_last && n == a.n_out - 1) {
-                    const float2 c2 = cmul_fma(y_pend, a.vtab[jt]);
-                    a.y_last[s] = make_float2(c2.x * inv_scale, c2.y * inv_scale);
+            const float dp = quad_demod_fast(y_pend, make_float2(px, py), a.gain, s_atan);
+            const bool st_ok = r8 == 0 && rsl != 0 && n_base >= 0;
+            const f32x2 dd{dp, d1_pend};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, dd), orsrc, st_ok ? 4 * n_base : OOB, 0, 0);
+            // carry for the next call: the composite FIR output of the stream's last output, computed
+            // directly (f32, composite taps) by the first wave of the workgroup that owns the last tile
+            if (a.y_last && bidx == tiles_per_stream - 1 && w == 0) {
+                const long long item0 = (a.n_out - 1) * D - a.n_lo + lead;       // relative to the stream's descriptor
+                __amdgpu_buffer_rsrc_t xr; int vdummy;
+                tile_geom(s, bidx, xr, vdummy);
+                float sx = 0.f, sy = 0.f;
+                for (int i = lane; i < a.T; i += 64) {
+                    const long long it = item0 + i;
+                    const int vo = (it < 0 || (lead && it == 0)) ? OOB : (int)(it * 8);
+                    const u32x2 xv = __builtin_amdgcn_raw_buffer_load_b64(xr, vo, 0, 0);
+                    const f32x2 xf = __builtin_bit_cast(f32x2, xv);
+                    const float2 c = a.ctaps[i];
+                    sx = __builtin_fmaf(c.x, xf.x, sx); sx = __builtin_fmaf(-c.y, xf.y, sx);
+                    sy = __builtin_fmaf(c.x, xf.y, sy); sy = __builtin_fmaf(c.y, xf.x, sy);
                 }
+                sx = wave_sum_f(sx); sy = wave_sum_f(sy);
+                if (lane == 0) a.y_last[s] = make_float2(sx, sy);
             }
         }
 
+        MF_STAMP(5);
         cur = nxt;
         if (!a.sched) nxt = nxt + Gd;
         s = s_nxt; bidx = b_nxt;
@@ -440,7 +502,24 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
             __threadfence();
         }
     }
+#ifdef GRHIP_STAMP
+    if (lane == 0 && g_mf_stamp_buf) {
+        unsigned long long *o = g_mf_stamp_buf + ((size_t)blockIdx.x * mf::WAVES + w) * 10;
+        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+        o[8] = st_begin; o[9] = mf_stamp_now();
+    }
+#endif
 }
+
+#ifdef GRHIP_STAMP
+// debug hook (not part of the ABI): where the stamp sums go; needs 10 u64 per wave
+extern "C" __attribute__((visibility("default"))) int grdbg_set_stamp_buffer_mfma(void *d_buf)
+{
+    unsigned long long *p = (unsigned long long *)d_buf;
+    GRHIP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mf_stamp_buf), &p, sizeof(p)));
+    return GRHIP_OK;
+}
+#endif
 
 static int g_mf_cus = 0;
 
