@@ -6,7 +6,7 @@ import numpy as np
 
 __all__ = [
     "GrhipError", "lib", "lib_path", "strerror", "device_count", "set_default_mode",
-    "MODE_FAST", "MODE_GENERIC", "MODE_FAST_VALU",
+    "MODE_FAST", "MODE_GENERIC", "MODE_FAST_VALU", "WORK_DONE",
     "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
     "clock_recovery_mm_ff", "clock_recovery_mm_cc", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "stream_to_streams", "streams_to_stream", "vector_to_streams", "stream_to_vector", "head",
@@ -16,6 +16,7 @@ __all__ = [
 MODE_FAST = 0
 MODE_GENERIC = 1
 MODE_FAST_VALU = 2     # FAST without the matrix cores (vector FMAs only)
+WORK_DONE = 0x7fffffff  # GRHIP_WORK_DONE: not an error, not an item count
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -578,17 +579,17 @@ class _copy_adapter(_Block):
         out = np.zeros(max(noutput_items, 1) * self.out_bytes, dtype=np.uint8)
         L = lib()
         L.grhip_copy_adapter_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        n = L.grhip_copy_adapter_work(self._h, int(noutput_items), _ptr(x), _ptr(out))
-        if n == -1:
-            return None                                    # WORK_DONE
-        _check(n)
+        n = _check(L.grhip_copy_adapter_work(self._h, int(noutput_items), _ptr(x), _ptr(out)))   # negative: always an error
+        if n == WORK_DONE:
+            return None
         return out[:n * self.out_bytes].view(x.dtype)
 
     def work_device(self, noutput_items, d_in, d_out, stream=None):
         L = lib()
         L.grhip_copy_adapter_work_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-        n = L.grhip_copy_adapter_work_device(self._h, int(noutput_items), _devptr(d_in), _devptr(d_out), _stream(stream))
-        return n if n == -1 else _check(n)
+        n = _check(L.grhip_copy_adapter_work_device(self._h, int(noutput_items), _devptr(d_in), _devptr(d_out),
+                                                    _stream(stream)))
+        return None if n == WORK_DONE else n
 
 
 class stream_to_vector(_copy_adapter):
@@ -603,7 +604,7 @@ class stream_to_vector(_copy_adapter):
 
 
 class head(_copy_adapter):
-    """gr.head(sizeof_stream_item, nitems): work() returns None (WORK_DONE, -1) once nitems have passed"""
+    """gr.head(sizeof_stream_item, nitems): work() / work_device() return None (WORK_DONE) once nitems have passed"""
 
     def __init__(self, sizeof_stream_item, nitems, device=0):
         _Block.__init__(self)

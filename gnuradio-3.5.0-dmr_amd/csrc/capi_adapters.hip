@@ -61,8 +61,9 @@ static int adapter_work(grhip_copy_adapter *h, int noutput_items, const void *in
     if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative item count");
     unsigned long long n = (unsigned long long)noutput_items;
     if (h->head) {
-        if (h->ncopied >= h->nitems) return -1;                                   // gr_head.cc:49-50: done
+        if (h->ncopied >= h->nitems) return GRHIP_WORK_DONE;                      // gr_head.cc:49-50: done (-1 there)
         n = std::min(h->nitems - h->ncopied, n);                                  // .cc:52
+        n = std::min(n, (unsigned long long)(GRHIP_WORK_DONE - 1));               // an item count is never the sentinel
     }
     if (n == 0) return 0;
     if (!in || !out) return fail(GRHIP_EINVAL, "null buffer");

@@ -223,15 +223,21 @@ void XlatingCore::reset()
 }
 
 // make sure d_rot covers outputs [pos, pos+n); *gtab = device pointer of phase(pos)
-int XlatingCore::ensure_rot(long long n, const float2 **gtab)
+int XlatingCore::ensure_rot(long long n, const float2 **gtab, hipStream_t st)
 {
     const long long CAP = 1ll << 25;
-    if (pos < tab_start) { tab_start = 0; tab_len = 0; gen_phase = cf(1.f, 0.f); gen_counter = 0; }
+    // The table is extended in place behind what earlier launches read; only when its front is
+    // rewritten (restart, re-anchor) may a launch still in flight on `st` be reading those entries.
+    bool rewrites_front = false;
+    if (pos < tab_start) { tab_start = 0; tab_len = 0; gen_phase = cf(1.f, 0.f); gen_counter = 0; rewrites_front = true; }
     long long tab_end = tab_start + tab_len;
     if (pos + n > tab_end) {
         if (pos == tab_end && tab_len > 0 && (pos + n - tab_start) > CAP) {
             tab_start = pos; tab_len = 0;   // re-anchor, generator state is already at pos
+            rewrites_front = true;
         }
+        if (tab_len == 0) rewrites_front = true;
+        if (rewrites_front && d_rot.p) GRHIP_HIP(hipStreamSynchronize(st));
         long long need = pos + n - (tab_start + tab_len);
         std::vector<cf> fresh((size_t)need);
         // gr_rotator::rotate (filter/gr_rotator.h:40-50), exact float recurrence
@@ -271,7 +277,7 @@ int XlatingCore::ensure_rot(long long n, const float2 **gtab)
 int XlatingCore::phase_before_pos(std::complex<float> *g)
 {
     const float2 *gtab = nullptr;
-    int rc = ensure_rot(1, &gtab);
+    int rc = ensure_rot(1, &gtab, nullptr);
     if (rc) return rc;
     cf ph;
     GRHIP_HIP(hipMemcpy(&ph, gtab, sizeof(ph), hipMemcpyDeviceToHost));
@@ -304,7 +310,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
                                  : (demod && mode_fast(mode) && use_tiled && premix && (batched || !prefer_ols));
     int rc = GRHIP_OK;
     if (!direct) {          // the direct demodulator epilogue needs no rotator phases
-        rc = ensure_rot(n_out, &gtab);
+        rc = ensure_rot(n_out, &gtab, st);
         if (rc) return rc;
     }
     if (mfma_now) {
@@ -610,10 +616,15 @@ int grhip_fir_filter_history(const grhip_fir_filter *h)
 
 int grhip_fir_filter_decimation(const grhip_fir_filter *h) { return h ? h->decim : GRHIP_EINVAL; }
 
-static int fir_apply_update(grhip_fir_filter *h)
+// `st`: the stream this work call will use.  install() rewrites the tap buffers with blocking copies on
+// the null stream, which do not wait for the handle's non-blocking streams: an earlier *_work_device
+// launch may still be reading them, so the streams are drained first.
+static int fir_apply_update(grhip_fir_filter *h, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(h->setter_mutex);
     if (!h->updated) return 0;
+    GRHIP_HIP(hipStreamSynchronize(st));
+    if (st != h->own_stream) GRHIP_HIP(hipStreamSynchronize(h->own_stream));
     int rc = h->install(h->new_taps);
     if (rc) return rc;
     h->updated = false;
@@ -627,7 +638,7 @@ int grhip_fir_filter_work_device(grhip_fir_filter *h, int noutput_items, const v
     if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
     int rc = h->bind();
     if (rc) return rc;
-    rc = fir_apply_update(h);
+    rc = fir_apply_update(h, h->pick(stream));
     if (rc < 0) return rc;
     if (rc == 1) return 0;   // history requirements may have changed (.cc.t:74-79)
     rc = h->run(d_in, d_out, noutput_items, h->decim, h->pick(stream));
@@ -640,7 +651,7 @@ int grhip_fir_filter_work(grhip_fir_filter *h, int noutput_items, const void *in
     if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
     int rc = h->bind();
     if (rc) return rc;
-    rc = fir_apply_update(h);
+    rc = fir_apply_update(h, h->own_stream);
     if (rc < 0) return rc;
     if (rc == 1) return 0;
     if (noutput_items == 0) return 0;
@@ -788,10 +799,12 @@ int grhip_freq_xlating_fir_filter_ccc_reset(grhip_freq_xlating_fir_filter_ccc *h
     return GRHIP_OK;
 }
 
-static int xl_apply_update(grhip_freq_xlating_fir_filter_ccc *h)
+static int xl_apply_update(grhip_freq_xlating_fir_filter_ccc *h, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(h->setter_mutex);
     if (!h->updated) return 0;
+    GRHIP_HIP(hipStreamSynchronize(st));         // see fir_apply_update
+    if (st != h->own_stream) GRHIP_HIP(hipStreamSynchronize(h->own_stream));
     // work(): set_history; build_composite_fir(); d_updated = false; return 0 (.cc.t:109-114).
     // NB the reference keeps the rotator's d_phase/d_counter and only replaces
     // d_phase_incr; XlatingCore::rebuild_keep_phase does the same.
@@ -810,7 +823,7 @@ int grhip_freq_xlating_fir_filter_ccc_work_device(grhip_freq_xlating_fir_filter_
     if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
     int rc = h->bind();
     if (rc) return rc;
-    rc = xl_apply_update(h);
+    rc = xl_apply_update(h, h->pick(stream));
     if (rc < 0) return rc;
     if (rc == 1) return 0;
     long long n = noutput_items;
@@ -827,7 +840,7 @@ int grhip_freq_xlating_fir_filter_ccc_work(grhip_freq_xlating_fir_filter_ccc *h,
     if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
     int rc = h->bind();
     if (rc) return rc;
-    rc = xl_apply_update(h);
+    rc = xl_apply_update(h, h->own_stream);
     if (rc < 0) return rc;
     if (rc == 1) return 0;
     if (noutput_items == 0) return 0;

@@ -78,7 +78,7 @@ struct XlatingCore {
         return GRHIP_OK;
     }
     void reset();
-    int ensure_rot(long long n, const float2 **gtab);
+    int ensure_rot(long long n, const float2 **gtab, hipStream_t st);
     int phase_before_pos(std::complex<float> *g);
     // fused demodulator on the pre-mixed accumulators (EPI_DEMOD): FAST mode, real prototype taps
     // (single-stream calls of a long filter go through the overlap-save engine instead; batched

@@ -12,11 +12,16 @@
 //   grhip_fft_vcc                            <- gr_fft_vcc (general/gr_fft_vcc.h:41-59)
 //   grhip_pfb_channelizer_ccf                <- gr_pfb_channelizer_ccf (filter/gr_pfb_channelizer_ccf.h:115-178)
 //
-// The scheduler hands a block at most half a 64 KiB buffer per call
-// (runtime/gr_block_executor.cc:76-78, runtime/gr_flat_flowgraph.cc:37,100), far
-// too little for a GPU launch.  Every wrapper therefore raises
-// output_multiple, which the flowgraph honours when it sizes buffers
-// (runtime/gr_flat_flowgraph.cc:102-104,118).
+// output_multiple is the REFERENCE's for every block (1; nsamples for fft_filter_ccc; the
+// channeliser's own), so a finite flowgraph produces exactly the items the reference block
+// produces, tail included.  The scheduler then hands a block at most half a 64 KiB buffer per
+// call (runtime/gr_block_executor.cc:76-78, runtime/gr_flat_flowgraph.cc:37,100): correct, but
+// launch-bound on a GPU.  An application that streams can opt in to larger calls
+// with grhip_set_batch_items(block, n) below: it multiplies output_multiple, which GNU Radio
+// 3.5 honours when it sizes buffers (runtime/gr_flat_flowgraph.cc:102-104,118) -- at the
+// documented price of every raised output_multiple in GNU Radio: when the upstream finishes,
+// fewer than one multiple of outputs can no longer be requested and that tail is dropped
+// (runtime/gr_block_executor.cc:335-348).
 #pragma once
 #include <cstring>
 #include <stdexcept>
@@ -39,8 +44,14 @@ inline void check(int rc)
     default: throw std::runtime_error(msg);
     }
 }
-const int BATCH_ITEMS = 1 << 16;     // output_multiple for the streaming blocks
 }  // namespace grhip_detail
+
+// opt-in batching (see the header comment): work() calls of n times the block's own output multiple
+template <class BLOCK_SPTR> inline void grhip_set_batch_items(const BLOCK_SPTR &b, int n)
+{
+    if (n < 1) throw std::invalid_argument("grhip_set_batch_items: n must be >= 1");
+    b->set_output_multiple(b->output_multiple() * n);
+}
 
 // ---------------------------------------------------------------------------
 // gr_fir_filter_XXX
@@ -56,7 +67,6 @@ protected:
         grhip_detail::check(grhip_fir_filter_create(&d_h, kind, decimation, (const float *)taps.data(), taps.size(),
                                                     device));
         set_history(grhip_fir_filter_history(d_h));          // set_history(d_fir->ntaps()), .cc.t:51
-        set_output_multiple(grhip_detail::BATCH_ITEMS);
     }
 public:
     ~grhip_fir_filter_base() { grhip_fir_filter_destroy(d_h); }
@@ -106,7 +116,6 @@ class grhip_freq_xlating_fir_filter_ccc_blk : public gr_sync_decimator {
         grhip_detail::check(grhip_freq_xlating_fir_filter_ccc_create(&d_h, decimation, (const float *)taps.data(),
                                                                      taps.size(), center_freq, sampling_freq, device));
         set_history(grhip_freq_xlating_fir_filter_ccc_history(d_h));
-        set_output_multiple(grhip_detail::BATCH_ITEMS);
     }
     friend grhip_freq_xlating_fir_filter_ccc_sptr grhip_make_freq_xlating_fir_filter_ccc(
         int, const std::vector<gr_complex> &, double, double, int);
@@ -145,7 +154,6 @@ class grhip_quadrature_demod_cf_blk : public gr_sync_block {
     {
         grhip_detail::check(grhip_quadrature_demod_cf_create(&d_h, gain, device));
         set_history(2);                                        // gr_quadrature_demod_cf.cc:37
-        set_output_multiple(grhip_detail::BATCH_ITEMS);
     }
     friend grhip_quadrature_demod_cf_sptr grhip_make_quadrature_demod_cf(float, int);
 public:
@@ -177,7 +185,6 @@ class grhip_clock_recovery_mm_ff_blk : public gr_block {
         grhip_detail::check(grhip_clock_recovery_mm_ff_create(&d_h, omega, gain_omega, mu, gain_mu,
                                                               omega_relative_limit, device));
         set_relative_rate(1.0 / omega);                        // .cc:64
-        set_output_multiple(4096);
     }
     friend grhip_clock_recovery_mm_ff_sptr grhip_make_clock_recovery_mm_ff(float, float, float, float, float, int);
 public:
@@ -227,7 +234,6 @@ class grhip_binary_slicer_fb_blk : public gr_sync_block {
                         gr_make_io_signature(1, 1, sizeof(unsigned char)))
     {
         grhip_detail::check(grhip_binary_slicer_fb_create(&d_h, device));
-        set_output_multiple(4096);
     }
     friend grhip_binary_slicer_fb_sptr grhip_make_binary_slicer_fb(int);
 public:
@@ -260,7 +266,6 @@ class grhip_clock_recovery_mm_cc_blk : public gr_block {
                                                               omega_relative_limit, device));
         set_relative_rate(1.0 / omega);                        // .cc:68
         set_history(3);                                        // .cc:69
-        set_output_multiple(1024);
     }
     friend grhip_clock_recovery_mm_cc_sptr grhip_make_clock_recovery_mm_cc(float, float, float, float, float, int);
     float get(int (*f)(grhip_clock_recovery_mm_cc *, float *)) const
@@ -411,7 +416,6 @@ class grhip_correlate_access_code_bb_blk : public gr_sync_block {
         // the reference throws std::out_of_range("access_code is > 64 bits") (.cc:54-57)
         grhip_detail::check(grhip_correlate_access_code_bb_create(&d_h, access_code.data(), access_code.size(),
                                                                   threshold, device));
-        set_output_multiple(4096);
     }
     friend grhip_correlate_access_code_bb_sptr grhip_make_correlate_access_code_bb(const std::string &, int, int);
 public:
@@ -445,7 +449,6 @@ class grhip_fft_vcc_blk : public gr_sync_block {
                         gr_make_io_signature(1, 1, fft_size * sizeof(gr_complex)))
     {
         grhip_detail::check(grhip_fft_vcc_create(&d_h, fft_size, forward, window.data(), window.size(), shift, device));
-        set_output_multiple(16);
     }
     friend grhip_fft_vcc_sptr grhip_make_fft_vcc(int, bool, const std::vector<float> &, bool, int);
 public:
@@ -511,7 +514,6 @@ class grhip_pfb_decimator_ccf_blk : public gr_sync_block {
     {
         grhip_detail::check(grhip_pfb_decimator_ccf_create(&d_h, decim, taps.data(), taps.size(), channel, device));
         set_history(grhip_pfb_decimator_ccf_history(d_h));           // .cc:108
-        set_output_multiple(1024);
     }
     friend grhip_pfb_decimator_ccf_sptr grhip_make_pfb_decimator_ccf(unsigned, const std::vector<float> &, unsigned, int);
 public:
@@ -549,7 +551,7 @@ class grhip_pfb_channelizer_ccf_blk : public gr_block {
                                                              device));
         set_history(grhip_pfb_channelizer_ccf_history(d_h));
         set_relative_rate(1.0 / (numchans / oversample_rate));    // set_relative_rate(1.0/intp), .cc:62
-        set_output_multiple(grhip_pfb_channelizer_ccf_output_multiple(d_h) * 1024);
+        set_output_multiple(grhip_pfb_channelizer_ccf_output_multiple(d_h));     // gr_pfb_channelizer_ccf.cc:92
     }
     friend grhip_pfb_channelizer_ccf_sptr grhip_make_pfb_channelizer_ccf(unsigned, const std::vector<float> &, float, int);
 public:

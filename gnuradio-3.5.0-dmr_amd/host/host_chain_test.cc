@@ -56,7 +56,7 @@ static int test_errors()
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::cerr << "usage: host_chain_test <dir> <chain|errors|widened>\n"; return 2; }
+    if (argc < 3) { std::cerr << "usage: host_chain_test <dir> <chain|errors|widened|tail>\n"; return 2; }
     std::string dir = argv[1], mode = argv[2];
     if (mode == "errors") return test_errors();
     if (mode == "widened") {
@@ -97,6 +97,30 @@ int main(int argc, char **argv)
         return 0;
     }
 
+    if (mode == "tail") {
+        // a SHORT finite stream under the reference's scheduler semantics (whole output multiples only, a block
+        // is done once one multiple can no longer be requested; 4096-item calls = half a 64 KiB buffer):
+        // with the reference's output_multiple every item comes out; the opt-in batching drops a tail
+        std::vector<gr_complex> x = slurp<gr_complex>(dir + "/x.c64");
+        std::vector<gr_complex> taps = slurp<gr_complex>(dir + "/taps.c64");
+        std::vector<double> p = slurp<double>(dir + "/params.f64");
+        {
+            gr_block_sptr xl = grhip_make_freq_xlating_fir_filter_ccc((int)p[0], taps, p[1], p[2]);
+            gr_block_sptr qd = grhip_make_quadrature_demod_cf((float)p[3]);
+            if (xl->output_multiple() != 1 || qd->output_multiple() != 1) { std::cerr << "output_multiple\n"; return 1; }
+            grhip_linear_flowgraph g(4096, false); g.connect(xl); g.connect(qd);
+            dump(dir + "/demod_ref_multiple.f32", g.run(x.data(), x.size()));
+        }
+        {
+            gr_block_sptr xl = grhip_make_freq_xlating_fir_filter_ccc((int)p[0], taps, p[1], p[2]);
+            gr_block_sptr qd = grhip_make_quadrature_demod_cf((float)p[3]);
+            grhip_set_batch_items(xl, 1024);
+            grhip_linear_flowgraph g(4096, false); g.connect(xl); g.connect(qd);
+            dump(dir + "/demod_batched.f32", g.run(x.data(), x.size()));
+        }
+        std::cout << "tail ok\n";
+        return 0;
+    }
     std::vector<gr_complex> x = slurp<gr_complex>(dir + "/x.c64");
     std::vector<gr_complex> taps = slurp<gr_complex>(dir + "/taps.c64");
     std::vector<double> p = slurp<double>(dir + "/params.f64");

@@ -58,6 +58,11 @@ extern "C" {
 #define GRHIP_ERUNTIME (-3) /* std::runtime_error (HIP call failed) */
 #define GRHIP_ENOMEM (-4)   /* std::bad_alloc        */
 #define GRHIP_ENODEV (-5)   /* no usable gfx950 device / HIP runtime */
+/* NOT an error: a work call's way to say WORK_DONE (runtime/gr_block.h:63-66, where it is -1).  The
+ * reference's -1 would collide with GRHIP_EINVAL, so the ABI reports it as the largest int, which no
+ * call can produce as an item count (grhip_head never copies more than INT_MAX - 1 items per call).
+ * Every negative return is an error. */
+#define GRHIP_WORK_DONE 0x7fffffff
 
 GRHIP_API const char *grhip_strerror(int status);
 /* thread-local detail of the last failing call on this thread ("" if none) */
@@ -271,7 +276,8 @@ GRHIP_API int grhip_unpack_k_bits_bb_work_device(grhip_unpack_k_bits_bb *h, int 
  *       general/gr_stream_to_vector.cc:31-60: gr_sync_decimator, work = one memcpy: grouping items into
  *       vectors moves no data;
  *   gr_make_head(size_t sizeof_stream_item, unsigned long long nitems)
- *       general/gr_head.cc:31-62: copies until nitems have passed, then work() returns -1 (WORK_DONE);
+ *       general/gr_head.cc:31-62: copies until nitems have passed, then work() returns WORK_DONE --
+ *       GRHIP_WORK_DONE here (the reference's -1 is an error code of this ABI);
  *   gr_make_vector_to_streams(size_t item_size, size_t nstreams)
  *       general/gr_vector_to_streams.cc:31-70: item j of every input vector goes to stream j -- the data
  *       movement of gr_stream_to_streams: create it with grhip_stream_adapter_create(split = 1, ...).

@@ -241,9 +241,16 @@ def test_remaining_harness_adapters(gpu):
     d = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev)
     o = torch.zeros_like(d)
     h2 = gpu.head(8, 1000)
-    assert h2.work_device(4096, d, o, st) == 1000 and h2.work_device(4096, d, o, st) == -1
+    assert h2.work_device(4096, d, o, st) == 1000 and h2.work_device(4096, d, o, st) is None
     st.synchronize()
     assert torch.equal(o[:1000], d[:1000]) and float(o[1000:].abs().sum()) == 0.0
+    # WORK_DONE has a code of its own (GRHIP_WORK_DONE); an invalid argument is an error, never a quiet end of stream
+    h3 = gpu.head(8, 1000)
+    with pytest.raises(gpu.GrhipError):
+        h3.work_device(16, None, o, st)                  # null input buffer
+    with pytest.raises(gpu.GrhipError):
+        h3.work_device(-1, d, o, st)
+    assert h3.work_device(16, d, o, st) == 16            # the failed calls consumed nothing
 
 
 def test_binary_slicer_vector_and_tail_paths(gpu, po):

@@ -533,3 +533,30 @@ def test_high_decimation_kernel_random_shapes(gpu, po, wl):
         assert got.shape == ref.shape, (kind, ntaps, decim, n)
         err = np.abs(got - ref).max()
         assert err <= TOL * max(np.abs(ref).max(), 1e-3 * bound), (kind, ntaps, decim, n, err)
+
+
+def test_set_taps_does_not_tear_a_launch_in_flight(gpu, po):
+    """the update path rewrites the device tap buffers with blocking null-stream copies; a
+    work_device() launch still running on the handle's (non-blocking) stream must be drained first"""
+    import torch
+    rng = np.random.default_rng(99)
+    ntaps, decim, n = 200, 1, 3_000_000
+    x = _rand_c(rng, n + ntaps - 1)
+    t_old = rng.uniform(-1, 1, ntaps).astype(np.float32)
+    t_new = (-t_old[::-1] * 3).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    d_x = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev)
+    d_y = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+    d_y2 = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+    blk = gpu.fir_filter_ccf(decim, t_old)
+    blk.set_mode(gpu.MODE_GENERIC)           # the slow kernel: several ms in flight
+    assert blk.work_device(n, d_x, d_y, st) == n
+    blk.set_taps(t_new)
+    assert blk.work_device(n, d_x, d_y2, st) == 0        # applies the update, produces nothing (.cc.t:74-79)
+    assert blk.work_device(n, d_x, d_y2, st) == n
+    st.synchronize()
+    got_old = d_y.cpu().numpy().reshape(-1).view(np.complex64)
+    got_new = d_y2.cpu().numpy().reshape(-1).view(np.complex64)
+    assert bits_equal(got_old, po.fir_ccf(t_old, x, n, decim))
+    assert bits_equal(got_new, po.fir_ccf(t_new, x, n, decim))

@@ -89,3 +89,27 @@ def test_cpp_widened_blocks_through_block_interface(exe, tmp_path, po, wl):
     # framer_sink_1 -> gr_msg_queue: arg1 = whitener offset, payload bytes, in order
     flat = b"".join(bytes([w, len(pl) & 0xFF, len(pl) >> 8]) + pl for w, pl in po.FramerSink1().work(flagged))
     assert (tmp_path / "messages.bin").read_bytes() == flat and len(flat) > 1000
+
+
+def test_cpp_short_stream_keeps_its_tail(exe, tmp_path, po, wl):
+    """a finite flowgraph shorter than the old 65536-item output multiple produced nothing.  The wrappers
+    now keep the reference's output_multiple (1): under the reference's scheduler rules (4096-item calls, whole
+    multiples, done when one multiple can no longer be asked for) every output comes out; the opt-in
+    grhip_set_batch_items() trades the tail for larger calls, as any raised output_multiple does in GNU Radio."""
+    c = wl.CFG2
+    n = 30_001 * 4
+    x = wl.fsk4_capture(n, stream_id=5)
+    taps = wl.cfg2_proto_taps()
+    x.tofile(tmp_path / "x.c64"); taps.tofile(tmp_path / "taps.c64")
+    np.array([c["decim"], c["center_freq"], c["fs"], c["demod_gain"]], np.float64).tofile(tmp_path / "params.f64")
+    r = subprocess.run([exe, str(tmp_path), "tail"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = po.chain_xlating_demod(c["decim"], taps, c["center_freq"], c["fs"], c["demod_gain"], x)
+    dem = np.fromfile(tmp_path / "demod_ref_multiple.f32", np.float32)
+    assert len(dem) == len(ref) == 30_001                        # nothing lost (the reference loses nothing here either)
+    ok, worst = demod_close(dem, ref)
+    assert ok, worst
+    bat = np.fromfile(tmp_path / "demod_batched.f32", np.float32)
+    assert len(bat) == (30_001 // 1024) * 1024                   # whole multiples only: the documented price
+    ok, worst = demod_close(bat, ref[:len(bat)])
+    assert ok, worst
