@@ -5,6 +5,7 @@
 //   -> binary_slicer_fb -> correlate_access_code_bb (one fused kernel)
 // Streams are independent units; batching them is what fills the
 // device for the serial M&M stage.
+#include <algorithm>
 #include <complex>
 
 #include "digital_kernels.h"
@@ -30,6 +31,11 @@ struct grhip_dmr_chain : HandleBase {
     DevBuf d_demod, d_soft, d_mm, d_mm_init, d_counts, d_ystate, d_corr, d_scratch;
     size_t out_stride = 0;
     int mode = GRHIP_MODE_FAST;
+    // FAST modes: the capture is processed in PIPE_CHUNKS time slices; the clock recovery of slice c (second
+    // stream) runs beside the FIR of slice c+1
+    static constexpr int PIPE_CHUNKS = 8;
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_fir[PIPE_CHUNKS] = {};
 };
 
 extern "C" {
@@ -66,8 +72,16 @@ int grhip_dmr_chain_create(grhip_dmr_chain **h, const grhip_dmr_chain_params *p,
         c->core.center_freq = p->center_freq; c->core.sampling_freq = p->sampling_freq;
         rc = c->core.build(device);
     }
-    if (!rc && !c->core.use_tiled)
-        rc = fail(GRHIP_EINVAL, "dmr_chain needs a decimation/tap count the tiled FIR supports");
+    if (!rc && !c->core.use_tiled && !c->core.use_mfma)
+        rc = fail(GRHIP_EINVAL, "dmr_chain needs a decimation/tap count a batched FIR engine supports");
+    if (!rc) {
+        hipError_t e = hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_end, hipEventDisableTiming);
+        for (int i = 0; i < grhip_dmr_chain::PIPE_CHUNKS && e == hipSuccess; ++i)
+            e = hipEventCreateWithFlags(&c->ev_fir[i], hipEventDisableTiming);
+        if (e != hipSuccess) rc = fail(GRHIP_ERUNTIME, "stream / event creation: %s", hipGetErrorString(e));
+    }
     size_t S = (size_t)n_streams;
     if (!rc) rc = c->d_demod.reserve(S * c->out_stride * 4);
     if (!rc) rc = c->d_soft.reserve(S * c->out_stride * 4);
@@ -93,6 +107,10 @@ void grhip_dmr_chain_destroy(grhip_dmr_chain *h)
     h->core.release();
     h->d_demod.release(); h->d_soft.release(); h->d_mm.release(); h->d_mm_init.release();
     h->d_counts.release(); h->d_ystate.release(); h->d_corr.release(); h->d_scratch.release();
+    if (h->st2) (void)hipStreamDestroy(h->st2);
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    for (auto &e : h->ev_fir) if (e) (void)hipEventDestroy(e);
     h->destroy_base();
     delete h;
 }
@@ -121,11 +139,42 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
     const long long hist = h->core.ntaps > 0 ? h->core.ntaps - 1 : 0;
     const float2 *x = (const float2 *)d_in - hist;
     float2 *ys = h->d_ystate.as<float2>();
+    hipStream_t st_mm = st;         // the stream the clock recovery and the correlator run on
     if (mode_fast(h->mode)) {
-        rc = h->core.run(h->mode, x, hist + (long long)n_samples, n_out, nullptr, h->d_demod.as<float>(),
-                         h->gain, ys, ys + S, h->tabs->atan_tab, st, h->S, (long long)stream_stride_items, hist,
-                         (long long)h->out_stride);
-        if (rc) return rc;
+        // FIR + demodulator in time slices on `st`; the clock recovery of a slice starts on the second stream as
+        // soon as that slice is written and continues from where the previous slice left it (mm_kernel's resume
+        // mode: same recurrence, same results, whatever the slicing).  The serial loop (one wavefront per capture,
+        // ~0.15 us per symbol) is the long pole: with the FIR beside it, a batch costs little more than it alone.
+        // The FIR keeps to one workgroup per CU here, so that the four clock-recovery waves of a CU find room.
+        const int NC = n_out >= 64 * 1024 ? grhip_dmr_chain::PIPE_CHUNKS : 1;
+        const long long Lc = ((n_out + NC - 1) / NC + 63) / 64 * 64;       // slice length in outputs (rows stay 16-byte aligned)
+        GRHIP_HIP(hipMemsetAsync(h->d_counts.p, 0, S * 2 * sizeof(int), st));
+        GRHIP_HIP(hipEventRecord(h->ev_begin, st));
+        GRHIP_HIP(hipStreamWaitEvent(h->st2, h->ev_begin, 0));
+        st_mm = NC > 1 ? h->st2 : st;
+        h->core.mf_wg_cap = NC > 1 ? 1 : 0;
+        for (int c = 0; c < NC; ++c) {
+            const long long o0 = (long long)c * Lc;
+            if (o0 >= n_out) break;
+            const long long len = std::min(Lc, n_out - o0);
+            const float2 *xc = x + o0 * h->core.decim;            // oldest history item of the slice
+            const float2 *yp = (c & 1) ? ys + S : ys;             // carry of the demodulator's previous sample
+            float2 *yl = (c & 1) ? ys : ys + S;
+            rc = h->core.run(h->mode, xc, hist + len * h->core.decim, len, nullptr, h->d_demod.as<float>() + o0,
+                             h->gain, yp, yl, h->tabs->atan_tab, st, h->S, (long long)stream_stride_items,
+                             c == 0 ? hist : 0, (long long)h->out_stride);
+            if (rc) { h->core.mf_wg_cap = 0; return rc; }
+            if (NC > 1) {
+                GRHIP_HIP(hipEventRecord(h->ev_fir[c], st));
+                GRHIP_HIP(hipStreamWaitEvent(h->st2, h->ev_fir[c], 0));
+            }
+            // 2) M&M clock recovery, one wavefront per stream, over what has been demodulated so far
+            rc = launch_mm(h->d_mm.as<MMState>(), h->S, (int)n_out, (int)(o0 + len), h->d_demod.as<float>(),
+                           (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
+                           h->d_counts.as<int>(), h->tabs->mmse_rev, st_mm, 1);
+            if (rc) { h->core.mf_wg_cap = 0; return rc; }
+        }
+        h->core.mf_wg_cap = 0;
     } else {
         // generic order: explicit zero history in a scratch row, one stream at a time
         rc = h->d_scratch.reserve((size_t)(hist + (long long)n_samples) * sizeof(float2));
@@ -140,21 +189,24 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
                              h->tabs->atan_tab, st);
             if (rc) return rc;
         }
+        // 2) M&M clock recovery, one wavefront per stream
+        rc = launch_mm(h->d_mm.as<MMState>(), h->S, (int)n_out, (int)n_out, h->d_demod.as<float>(),
+                       (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
+                       h->d_counts.as<int>(), h->tabs->mmse_rev, st);
+        if (rc) return rc;
     }
-
-    // 2) M&M clock recovery, one wavefront per stream
-    rc = launch_mm(h->d_mm.as<MMState>(), h->S, (int)n_out, (int)n_out, h->d_demod.as<float>(),
-                   (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
-                   h->d_counts.as<int>(), h->tabs->mmse_rev, st);
-    if (rc) return rc;
 
     // 3) slicer + access-code correlator on the symbols each stream produced
     rc = launch_correlate(h->cp, h->d_corr.as<CorrState>(), h->S, nullptr, h->d_soft.as<float>(),
                           (long long)h->out_stride, d_bits, (long long)bits_stride, n_out,
-                          h->d_counts.as<int>(), 2, st);
+                          h->d_counts.as<int>(), 2, st_mm);
     if (rc) return rc;
     GRHIP_HIP(hipMemcpy2DAsync(d_nbits, sizeof(int), h->d_counts.p, 2 * sizeof(int), sizeof(int), S,
-                               hipMemcpyDeviceToDevice, st));
+                               hipMemcpyDeviceToDevice, st_mm));
+    if (st_mm != st) {          // the caller's stream continues when the second one is done
+        GRHIP_HIP(hipEventRecord(h->ev_end, st_mm));
+        GRHIP_HIP(hipStreamWaitEvent(st, h->ev_end, 0));
+    }
     return GRHIP_OK;
 }
 

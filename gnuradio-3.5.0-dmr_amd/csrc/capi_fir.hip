@@ -327,6 +327,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         const uintptr_t o = demod ? (uintptr_t)d_demod : (uintptr_t)d_y;
         a.vec_store = demod ? ((o & 7) == 0 && !(out_stride & 1)) : ((o & 15) == 0 && !(out_stride & 1));
         a.sched = mf_sched.get();
+        a.max_wg_per_cu = mf_wg_cap;
         rc = launch_fir_mfma(decim, ntaps, true, demod ? EPI_DEMOD : EPI_ROTATE, a, st);
         if (rc) return rc;
         pos += n_out;

@@ -15,11 +15,11 @@ struct MMState {
 
 // one wave per stream; stream s reads in + s*in_stride, writes out + s*out_stride,
 // state[s], counts[2*s] = produced, counts[2*s+1] = consumed.
-// n_in_ptr (optional, device int per stream with stride n_in_ptr_stride): when
-// non-null the number of input items is min(ninput_items, n_in_ptr[s*stride]).
+// resume != 0: counts[] hold the stream's totals so far, the call continues from there with
+// noutput_items / ninput_items counted from the stream's start (see mm_kernel).
 int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items, const float *in,
               long long in_stride, float *out, long long out_stride, int *counts,
-              const float *mmse_rev, hipStream_t st);
+              const float *mmse_rev, hipStream_t st, int resume = 0);
 
 int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipStream_t st);
 // pager_slicer_fb: d_avg[s] carried in device memory; streams s at in + s*in_stride / out + s*out_stride

@@ -25,10 +25,9 @@ namespace grhip {
 //  * outputs are collected in LDS and written out coalesced once per window.
 // Every float operation is a single unfused IEEE op in the reference's order: bit-exact.
 // ===========================================================================
-constexpr int MM_CH = 4096;
+constexpr int MM_CH = 2048;        // (8 KB: four such waves fit in the LDS a FIR workgroup leaves on a CU)
 constexpr int MM_NTAPS = 8;
 constexpr int MM_NSTEPS = 128;
-constexpr int MM_OUT = 1024;        // outputs buffered per window (a window of 4096 inputs yields ~MM_CH/omega)
 
 __device__ __forceinline__ float mm_slice_mul(float s, float v) { return s < 0 ? -v : v; }     // slice(s) * v, slice = -1 / +1
 
@@ -39,18 +38,38 @@ __device__ __forceinline__ float row_shl(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
 }
 
+// One symbol costs its INSTRUCTION COUNT (a lone wavefront issues one instruction every 4-5 cycles),
+// so the loop body is kept to what the recurrence needs (~45 instructions, 75 in round 1):
+//  * the interpolator phase of the NEXT symbol is formed at the end of the current one (mu is in
+//    [0, 1) from then on: no clamp in the loop; the clamp guards the caller's initial mu only);
+//  * slice(a) * b is b with its sign flipped by the sign bit of a (a is never -0: a sum that
+//    started from +0), two bit operations instead of compare / select / multiply;
+//  * the window and end-of-input tests are ONE unsigned compare, the output count a countdown;
+//  * outputs collect in a register (lane c of it = symbol c of a group of 64) and go to HBM
+//    with one coalesced store per group: no LDS traffic per symbol.
+// resume != 0: counts[2s] / counts[2s+1] hold what stream s has produced / consumed so far; the
+// call continues from there (in and out are indexed from the stream's start) and adds to them.
+// This is how the chain overlaps the FIR of later parts of a capture with the clock recovery of
+// earlier ones; the recurrence is the same whatever the chunking.
 __global__ void __launch_bounds__(64)
 mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, const float *__restrict__ in,
           long long in_stride, float *__restrict__ out, long long out_stride, int *__restrict__ counts,
-          const float *__restrict__ mmse_rev)
+          const float *__restrict__ mmse_rev, int resume)
 {
     __shared__ float s_in[MM_CH];
     __shared__ float s_taps[MM_NTAPS * (MM_NSTEPS + 1)];
-    __shared__ float s_out[MM_OUT];
 
     const int s = blockIdx.x, lane = threadIdx.x;
-    const float *__restrict__ x = in + (long long)s * in_stride;
-    float *__restrict__ y = out + (long long)s * out_stride;
+    __builtin_amdgcn_s_setprio(3);      // latency-bound: when it shares a SIMD with a throughput kernel, it goes first
+    int oo0 = 0, ii0 = 0;
+    if (resume) {
+        oo0 = __builtin_amdgcn_readfirstlane(counts[2 * s]);
+        ii0 = __builtin_amdgcn_readfirstlane(counts[2 * s + 1]);
+    }
+    const float *__restrict__ x = in + (long long)s * in_stride + ii0;
+    float *__restrict__ y = out + (long long)s * out_stride + oo0;
+    noutput_items -= oo0;
+    ninput_items -= ii0;
 
     for (int i = lane; i < MM_NTAPS * (MM_NSTEPS + 1); i += 64) s_taps[i] = mmse_rev[i];
 
@@ -62,10 +81,13 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
     const int ni = ninput_items - MM_NTAPS;           // .cc:113
     const int k = lane & 7;                           // this lane's tap of the interpolator
     const float *tapcol = &s_taps[k * (MM_NSTEPS + 1)];
+    // interpolate(&in[ii], d_mu): imu = (int) rint(mu * NSTEPS)   (gri_mmse_fir_interpolator.cc:64)
+    int imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
+    imu = imu < 0 ? 0 : (imu > MM_NSTEPS ? MM_NSTEPS : imu);
     bool done = !(oo < noutput_items && ii < ni);
 
     while (!done) {
-        const int base = ii, obase = oo;
+        const int base = ii;
         // sixteen independent loads in flight per lane: one load per loop trip would make the lone wave wait for
         // memory latency 64 times per window
         for (int ib = lane; ib < MM_CH; ib += 64 * 16) {
@@ -80,39 +102,48 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
             for (int q = 0; q < 16; ++q) s_in[ib + 64 * q] = v[q];
         }
         __syncthreads();
+        // symbols may start at ii in [base, min(ni - 1, base + MM_CH - MM_NTAPS)]: one unsigned compare
         const int lim = base + MM_CH - MM_NTAPS;
+        const unsigned span = (unsigned)((ni - 1 < lim ? ni - 1 : lim) - base);
         const float *xk = &s_in[k - base];
-        while (oo < noutput_items && ii < ni && ii <= lim && ii >= base && oo - obase < MM_OUT) {
-            // interpolate(&in[ii], d_mu): imu = (int) rint(mu * NSTEPS)
-            int imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
-            imu = imu < 0 ? 0 : (imu > MM_NSTEPS ? MM_NSTEPS : imu);
-            // lanes 0..7: (0 + tap k * sample k) -- the fma rounds the product once and adds an
-            // exact zero, i.e. the reference's `acc = 0; acc += t*x` including the sign of a
-            // zero product; using it for the upper partner too changes nothing (a + -0 == a + +0
-            // unless a is a zero, and then both give +0)
-            const float p = __builtin_fmaf(tapcol[imu], xk[ii], 0.0f);
-            const float acc = p + row_shl<4>(p);                          // lanes 0..3: acc_j
-            float o = acc + row_shl<1>(acc);
-            o = o + row_shl<2>(acc);
-            o = o + row_shl<3>(acc);
-            o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o), 0));
-            s_out[oo - obase] = o;
-            // .cc:120  slice(last)*o - slice(o)*last; slice(o) = +-1 is the sign of o glued onto
-            // 1.0 (o is never -0: it is a sum that started from +0), and since slice(o)*last is
-            // exact the fma below rounds exactly like the reference's subtraction
-            const float so = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, o) & 0x80000000u) | 0x3f800000u);
-            const float mm_val = __builtin_fmaf(-so, last, mm_slice_mul(last, o));
-            last = o;
-            omega = omega + gain_omega * mm_val;                              // .cc:123
-            omega = omega_mid + branchless_clip(omega - omega_mid, rel);      // .cc:124
-            mu = mu + omega + gain_mu * mm_val;                               // .cc:125
-            const float fl = __builtin_floorf(mu);
-            ii = __builtin_amdgcn_readfirstlane(ii + (int)fl);                // .cc:127
-            mu = mu - fl;                                                     // .cc:128
-            oo++;
+        while (oo < noutput_items && (unsigned)(ii - base) <= span) {
+            const int room = noutput_items - oo;
+            const int grp = room < 64 ? room : 64;
+            float obuf = 0.f;
+            int c = 0;
+            do {
+                // lanes 0..7: (0 + tap k * sample k) -- the fma rounds the product once and adds an
+                // exact zero, i.e. the reference's `acc = 0; acc += t*x` including the sign of a
+                // zero product
+                const float p = __builtin_fmaf(tapcol[imu], xk[ii], 0.0f);
+                const float acc = p + row_shl<4>(p);                          // lanes 0..3: acc_j
+                float o = acc + row_shl<1>(acc);
+                o = o + row_shl<2>(acc);
+                o = o + row_shl<3>(acc);
+                const unsigned ob = (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, o), 0);
+                // (lane select through M0: a second SGPR operand would break the one-scalar-operand rule of gfx9 VALU)
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(obuf) : "s"(ob), "s"(c));
+                // .cc:120  mm_val = slice(last) * o - slice(o) * last, slice(x) = x < 0 ? -1 : 1.
+                // Neither o nor last is ever -0 (sums that started from +0), so multiplying by
+                // slice(a) is flipping the sign by a's sign bit; the two products are exact and the
+                // subtraction rounds once, as in the reference.
+                const unsigned lb = __builtin_bit_cast(unsigned, last);
+                const float t1 = __builtin_bit_cast(float, ob ^ (lb & 0x80000000u));
+                const float t2 = __builtin_bit_cast(float, lb ^ (ob & 0x80000000u));
+                const float mm_val = t1 - t2;
+                last = __builtin_bit_cast(float, ob);
+                omega = omega + gain_omega * mm_val;                              // .cc:123
+                omega = omega_mid + branchless_clip(omega - omega_mid, rel);      // .cc:124
+                mu = mu + omega + gain_mu * mm_val;                               // .cc:125
+                const float fl = __builtin_floorf(mu);
+                ii = __builtin_amdgcn_readfirstlane(ii + (int)fl);                // .cc:127
+                mu = mu - fl;                                                     // .cc:128
+                imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);                // next symbol's phase: mu is in [0, 1)
+                ++c;
+            } while (c < grp && (unsigned)(ii - base) <= span);
+            if (lane < c) y[oo + lane] = obuf;
+            oo += c;
         }
-        __syncthreads();
-        for (int i = lane; i < oo - obase; i += 64) y[obase + i] = s_out[i];
         done = !(oo < noutput_items && ii < ni);
         if (ii < 0) done = true;     // the reference would read before its buffer here
         __syncthreads();
@@ -121,18 +152,18 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
         MMState so = st;
         so.mu = mu; so.omega = omega; so.last_sample = last;
         state[s] = so;
-        counts[2 * s + 0] = oo;
-        counts[2 * s + 1] = ii;          // consume_each(ii)
+        counts[2 * s + 0] = oo0 + oo;
+        counts[2 * s + 1] = ii0 + ii;          // consume_each(ii)
     }
 }
 
 int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items, const float *in,
               long long in_stride, float *out, long long out_stride, int *counts, const float *mmse_rev,
-              hipStream_t st)
+              hipStream_t st, int resume)
 {
     if (n_streams <= 0) return GRHIP_OK;
     hipLaunchKernelGGL(mm_kernel, dim3(n_streams), dim3(64), 0, st, state, noutput_items, ninput_items, in,
-                       in_stride, out, out_stride, counts, mmse_rev);
+                       in_stride, out, out_stride, counts, mmse_rev, resume);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
 }

@@ -90,6 +90,7 @@ struct FirMfmaArgs {
     const float *atan_tab;
     int vec_store;          // (unused: outputs go through buffer stores, dword alignment suffices)
     unsigned *sched;        // tile queue counters (as FirTiledArgs::sched), or null
+    int max_wg_per_cu;      // 0: as many as fit (2); 1: leave half of every CU to a kernel running beside this one
 };
 bool mfma_supported(int decim, int ntaps);
 int launch_fir_mfma(int decim, int ntaps, bool premix, int epi, const FirMfmaArgs &a, hipStream_t st);

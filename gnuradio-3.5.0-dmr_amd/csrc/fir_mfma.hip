@@ -542,6 +542,7 @@ static int launch_mfma_inst(const FirMfmaArgs &a, hipStream_t st)
     const long long tiles = ((a.n_out + mf::NTE - 1) / mf::NTE) * a.n_streams;
     int wgs = (160 * 1024) / (G::LDS + 256);
     if (wgs > 2) wgs = 2;
+    if (a.max_wg_per_cu > 0 && wgs > a.max_wg_per_cu) wgs = a.max_wg_per_cu;
     if (wgs < 1) wgs = 1;
     long long grid = (long long)wgs * g_mf_cus;
     if (grid > tiles) grid = tiles;
