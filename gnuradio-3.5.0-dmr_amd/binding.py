@@ -9,7 +9,7 @@ __all__ = [
     "MODE_FAST", "MODE_GENERIC", "MODE_FAST_VALU", "WORK_DONE",
     "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
-    "clock_recovery_mm_ff", "clock_recovery_mm_cc", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "stream_to_streams", "streams_to_stream", "vector_to_streams", "stream_to_vector", "head",
+    "clock_recovery_mm_ff", "clock_recovery_mm_cc", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "framer_sink_1_batch", "stream_to_streams", "streams_to_stream", "vector_to_streams", "stream_to_vector", "head",
     "fft_vcc", "fft_filter_ccc", "pfb_channelizer_ccf", "pfb_decimator_ccf", "dmr_chain", "run_sync_block",
 ]
 
@@ -617,6 +617,43 @@ class head(_copy_adapter):
         _check(lib().grhip_head_reset(self._h))
 
 
+class framer_sink_1_batch(_Block):
+    """multi-capture gr.framer_sink_1: run_device() frames n_streams item streams in one go (every stream from
+    the search state); messages() -> [[(whitener_offset, payload bytes), ...] per stream]"""
+    _destroy = "grhip_framer_sink_1_batch_destroy"
+
+    def __init__(self, n_streams, max_items_per_stream, device=0):
+        _Block.__init__(self)
+        L = lib()
+        L.grhip_framer_sink_1_batch_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_int]
+        _check(L.grhip_framer_sink_1_batch_create(C.byref(self._h), int(n_streams), int(max_items_per_stream), int(device)))
+        self.n_streams = int(n_streams)
+
+    def run_device(self, d_in, stream_stride_items, d_nitems, n_items_max, stream=None, nitems_stride=1):
+        L = lib()
+        L.grhip_framer_sink_1_batch_run_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int,
+                                                           C.c_size_t, C.c_void_p]
+        _check(L.grhip_framer_sink_1_batch_run_device(self._h, _devptr(d_in), int(stream_stride_items), _devptr(d_nitems),
+                                                      int(nitems_stride), int(n_items_max), _stream(stream)))
+
+    def messages(self, stream=None):
+        L = lib()
+        L.grhip_framer_sink_1_batch_fetch.argtypes = [C.c_void_p, C.c_void_p]
+        L.grhip_framer_sink_1_batch_count.argtypes = [C.c_void_p, C.c_int]
+        L.grhip_framer_sink_1_batch_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int]
+        _check(L.grhip_framer_sink_1_batch_fetch(self._h, _stream(stream)))
+        buf = np.zeros(4096, np.uint8)
+        out = []
+        for s in range(self.n_streams):
+            msgs = []
+            for i in range(_check(L.grhip_framer_sink_1_batch_count(self._h, s))):
+                w = C.c_int(0)
+                ln = _check(L.grhip_framer_sink_1_batch_get(self._h, s, i, C.byref(w), _ptr(buf), 4096))
+                msgs.append((w.value, buf[:ln].tobytes()))
+            out.append(msgs)
+        return out
+
+
 class framer_sink_1(_Block):
     """gr.framer_sink_1(msgq): header + payload extraction after the correlator's flag bit.
     The reference inserts gr.message objects into `msgq`; here work() / work_device() collect them
@@ -962,6 +999,12 @@ class dmr_chain(_Block):
 
     def set_mode(self, mode):
         _check(lib().grhip_dmr_chain_set_mode(self._h, int(mode)))
+
+    def set_four_level(self, enable, pager_alpha=0.001):
+        """4FSK tail: pager.slicer_fb(alpha) -> unpack_k_bits_bb(2) -> correlator; two output items per symbol"""
+        L = lib()
+        L.grhip_dmr_chain_set_four_level.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        _check(L.grhip_dmr_chain_set_four_level(self._h, int(bool(enable)), float(pager_alpha)))
 
     def run_device(self, d_in, n_samples, stream_stride_items, d_bits, bits_stride, d_nbits, stream=None):
         L = lib()

@@ -34,6 +34,10 @@ struct grhip_dmr_chain : HandleBase {
     // FAST modes: the capture is processed in PIPE_CHUNKS time slices; the clock recovery of slice c (second
     // stream) runs beside the FIR of slice c+1
     static constexpr int PIPE_CHUNKS = 8;
+    // 4FSK tail (grhip_dmr_chain_set_four_level): pager_slicer_fb -> unpack_k_bits(2) in front of the correlator
+    bool four_level = false;
+    float pager_alpha = 0.f;
+    DevBuf d_sym, d_dibits, d_avg, d_nbits2;
     hipStream_t st2 = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_fir[PIPE_CHUNKS] = {};
 };
@@ -107,6 +111,7 @@ void grhip_dmr_chain_destroy(grhip_dmr_chain *h)
     h->core.release();
     h->d_demod.release(); h->d_soft.release(); h->d_mm.release(); h->d_mm_init.release();
     h->d_counts.release(); h->d_ystate.release(); h->d_corr.release(); h->d_scratch.release();
+    h->d_sym.release(); h->d_dibits.release(); h->d_avg.release(); h->d_nbits2.release();
     if (h->st2) (void)hipStreamDestroy(h->st2);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
@@ -127,7 +132,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
     const size_t S = (size_t)h->S;
     const long long n_out = (long long)(n_samples / h->core.decim);
     if (n_out <= 0) { GRHIP_HIP(hipMemsetAsync(d_nbits, 0, S * sizeof(int), st)); return GRHIP_OK; }
-    if ((size_t)n_out > bits_stride) return fail(GRHIP_EINVAL, "bits_stride too small");
+    if ((size_t)n_out * (h->four_level ? 2 : 1) > bits_stride) return fail(GRHIP_EINVAL, "bits_stride too small");
 
     // fresh block state for every capture
     h->core.reset();
@@ -196,6 +201,28 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         if (rc) return rc;
     }
 
+    if (h->four_level) {
+        // 3') 4FSK: DC-tracking four-level slicer, dibit unpack, correlator on the bit stream (2 items per symbol)
+        GRHIP_HIP(hipMemsetAsync(h->d_avg.p, 0, S * sizeof(float), st_mm));                      // d_avg = 0 (pager_slicer_fb.cc:40)
+        rc = launch_pager_slicer(h->d_avg.as<float>(), h->S, h->pager_alpha, 1.0f - h->pager_alpha, h->d_soft.as<float>(),
+                                 (long long)h->out_stride, h->d_sym.as<unsigned char>(), (long long)h->out_stride, n_out, st_mm,
+                                 h->d_counts.as<int>(), 2);
+        if (rc) return rc;
+        rc = launch_unpack_k_bits_streams(2, h->S, h->d_sym.as<unsigned char>(), (long long)h->out_stride,
+                                          h->d_dibits.as<unsigned char>(), 2 * (long long)h->out_stride, n_out,
+                                          h->d_counts.as<int>(), 2, h->d_nbits2.as<int>(), 1, st_mm);
+        if (rc) return rc;
+        rc = launch_correlate(h->cp, h->d_corr.as<CorrState>(), h->S, h->d_dibits.as<unsigned char>(), nullptr,
+                              2 * (long long)h->out_stride, d_bits, (long long)bits_stride, 2 * n_out, h->d_nbits2.as<int>(), 1,
+                              st_mm);
+        if (rc) return rc;
+        GRHIP_HIP(hipMemcpyAsync(d_nbits, h->d_nbits2.p, S * sizeof(int), hipMemcpyDeviceToDevice, st_mm));
+        if (st_mm != st) {
+            GRHIP_HIP(hipEventRecord(h->ev_end, st_mm));
+            GRHIP_HIP(hipStreamWaitEvent(st, h->ev_end, 0));
+        }
+        return GRHIP_OK;
+    }
     // 3) slicer + access-code correlator on the symbols each stream produced
     rc = launch_correlate(h->cp, h->d_corr.as<CorrState>(), h->S, nullptr, h->d_soft.as<float>(),
                           (long long)h->out_stride, d_bits, (long long)bits_stride, n_out,
@@ -217,13 +244,31 @@ int grhip_dmr_chain_set_mode(grhip_dmr_chain *h, int mode)
     return GRHIP_OK;
 }
 
+int grhip_dmr_chain_set_four_level(grhip_dmr_chain *h, int enable, float pager_alpha)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    int rc = h->bind();
+    if (rc) return rc;
+    if (enable) {
+        const size_t S = (size_t)h->S;
+        if ((rc = h->d_sym.reserve(S * h->out_stride))) return rc;
+        if ((rc = h->d_dibits.reserve(S * 2 * h->out_stride))) return rc;
+        if ((rc = h->d_avg.reserve(S * sizeof(float)))) return rc;
+        if ((rc = h->d_nbits2.reserve(S * sizeof(int)))) return rc;
+    }
+    h->four_level = enable != 0;
+    h->pager_alpha = pager_alpha;
+    return GRHIP_OK;
+}
+
 int grhip_dmr_chain_intermediate(grhip_dmr_chain *h, int which, void **d_ptr, size_t *stride)
 {
     if (!h || !d_ptr || !stride) return fail(GRHIP_EINVAL, "null argument");
     *stride = h->out_stride;
     if (which == 0) *d_ptr = h->d_demod.p;
     else if (which == 1) *d_ptr = h->d_soft.p;
-    else return fail(GRHIP_EINVAL, "which must be 0 or 1");
+    else if (which == 2 && h->four_level) *d_ptr = h->d_sym.p;
+    else return fail(GRHIP_EINVAL, "which must be 0, 1 (or 2 with the 4FSK tail)");
     return GRHIP_OK;
 }
 

@@ -48,9 +48,8 @@ __device__ inline unsigned nib(unsigned w, int bit)
     return ((((w >> bit) & 0x01010101u) * 0x08040201u) >> 24) & 0xfu;
 }
 
-__global__ void __launch_bounds__(256)
-framer_pack_kernel(const unsigned char *__restrict__ in, long long n, unsigned *__restrict__ F, unsigned *__restrict__ D,
-                   long long nwords_padded)
+__device__ __forceinline__ void framer_pack_body(const unsigned char *__restrict__ in, long long n, unsigned *__restrict__ F,
+                                                 unsigned *__restrict__ D, long long nwords_padded)
 {
     for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < nwords_padded; w += (long long)gridDim.x * 256) {
         const long long b = w << 5;
@@ -75,6 +74,29 @@ framer_pack_kernel(const unsigned char *__restrict__ in, long long n, unsigned *
     }
 }
 
+__global__ void __launch_bounds__(256)
+framer_pack_kernel(const unsigned char *__restrict__ in, long long n, unsigned *__restrict__ F, unsigned *__restrict__ D,
+                   long long nwords_padded)
+{
+    framer_pack_body(in, n, F, D, nwords_padded);
+}
+
+// multi-capture form: blockIdx.y = stream; stream s has min(n_max, n_ptr[s * n_stride]) items (n_ptr may be null)
+__device__ __forceinline__ long long batch_items(const int *n_ptr, int n_stride, long long n_max, int s)
+{
+    if (!n_ptr) return n_max;
+    const long long v = n_ptr[(long long)s * n_stride];
+    return v < 0 ? 0 : (v < n_max ? v : n_max);
+}
+__global__ void __launch_bounds__(256)
+framer_pack_batch_kernel(const unsigned char *__restrict__ in, long long in_stride, const int *n_ptr, int n_stride, long long n_max,
+                         unsigned *__restrict__ F, unsigned *__restrict__ D, long long words_stride)
+{
+    const int s = blockIdx.y;
+    framer_pack_body(in + (long long)s * in_stride, batch_items(n_ptr, n_stride, n_max, s), F + (long long)s * words_stride,
+                     D + (long long)s * words_stride, words_stride);
+}
+
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -82,9 +104,8 @@ __device__ inline unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_r
 // bookkeeping is 32-bit scalar arithmetic (a lone wave issues about one instruction every five cycles, so
 // the instruction count per packet is what the walk costs).  F and D hold nwords = ceil(n/32) words plus two
 // zero words.  n < 2^31.
-__global__ void __launch_bounds__(64)
-framer_walk_kernel(const unsigned *__restrict__ F, const unsigned *__restrict__ D, unsigned n, FramerState *S,
-                   FramerMsg *msgs, FramerJob *jobs)
+__device__ __forceinline__ void framer_walk_body(const unsigned *__restrict__ F, const unsigned *__restrict__ D, unsigned n,
+                                                 FramerState *S, FramerMsg *msgs, FramerJob *jobs)
 {
     const unsigned lane = threadIdx.x;
     int mode = uni(S->mode), hdr_cnt = uni(S->hdr_cnt), pktlen = uni(S->pktlen), woff = uni(S->woff), bits_done = uni(S->bits_done);
@@ -206,6 +227,26 @@ framer_walk_kernel(const unsigned *__restrict__ F, const unsigned *__restrict__ 
         S->bits_done = bits_done; S->msg_count = msg_count; S->pool_used = pool_used; S->open_off = open_off;
         S->njobs = njobs;
     }
+}
+
+__global__ void __launch_bounds__(64)
+framer_walk_kernel(const unsigned *__restrict__ F, const unsigned *__restrict__ D, unsigned n, FramerState *S,
+                   FramerMsg *msgs, FramerJob *jobs)
+{
+    framer_walk_body(F, D, n, S, msgs, jobs);
+}
+
+// multi-capture form: one wavefront per stream (blockIdx.x = stream), every stream from the search state
+__global__ void __launch_bounds__(64)
+framer_walk_batch_kernel(const unsigned *__restrict__ F, const unsigned *__restrict__ D, long long words_stride, const int *n_ptr,
+                         int n_stride, long long n_max, FramerState *S, FramerMsg *msgs, FramerJob *jobs, long long rec_stride)
+{
+    const int s = blockIdx.x;
+    FramerState *st = S + s;
+    if (threadIdx.x == 0) *st = FramerState{};          // enter_search(): a capture is framed whole, from a fresh block
+    __syncthreads();
+    framer_walk_body(F + (long long)s * words_stride, D + (long long)s * words_stride, (unsigned)batch_items(n_ptr, n_stride, n_max, s), st,
+                     msgs + (long long)s * rec_stride, jobs + (long long)s * rec_stride);
 }
 
 // ---- segment-parallel walk (long calls) --------------------------------------------------------------
@@ -453,9 +494,8 @@ framer_emit_kernel(unsigned n, unsigned reccap, const FrRec *__restrict__ recs, 
 
 // payload bits -> bytes (.cc:158-162): one lane per packet byte; a byte shared with the previous call's
 // job keeps the bits that are already there
-__global__ void __launch_bounds__(256)
-framer_payload_kernel(const unsigned *__restrict__ D, const FramerState *S, const FramerJob *__restrict__ jobs,
-                      unsigned char *__restrict__ pool)
+__device__ __forceinline__ void framer_payload_body(const unsigned *__restrict__ D, const FramerState *S,
+                                                    const FramerJob *__restrict__ jobs, unsigned char *__restrict__ pool)
 {
     const unsigned njobs = S->njobs;
     for (unsigned j = blockIdx.x; j < njobs; j += gridDim.x) {
@@ -476,6 +516,22 @@ framer_payload_kernel(const unsigned *__restrict__ D, const FramerState *S, cons
             *dst = (unsigned char)out;
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+framer_payload_kernel(const unsigned *__restrict__ D, const FramerState *S, const FramerJob *__restrict__ jobs,
+                      unsigned char *__restrict__ pool)
+{
+    framer_payload_body(D, S, jobs, pool);
+}
+
+__global__ void __launch_bounds__(256)
+framer_payload_batch_kernel(const unsigned *__restrict__ D, long long words_stride, const FramerState *S,
+                            const FramerJob *__restrict__ jobs, long long rec_stride, unsigned char *__restrict__ pool,
+                            long long pool_stride)
+{
+    const int s = blockIdx.y;
+    framer_payload_body(D + (long long)s * words_stride, S + s, jobs + (long long)s * rec_stride, pool + (long long)s * pool_stride);
 }
 
 // after a fetch: drop the delivered messages, move the open packet to the front of the pool
@@ -675,6 +731,126 @@ int grhip_framer_sink_1_drain(grhip_framer_sink_1 *h, int max_msgs, int *whitene
         ++h->next_msg;
     }
     return k;
+}
+
+// ---- multi-capture entry: n_streams captures framed in one go (grid.y / blockIdx.x = stream) --------------
+struct grhip_framer_sink_1_batch : HandleBase {
+    int S = 0;
+    long long max_items = 0, words_stride = 0, rec_stride = 0, pool_stride = 0;
+    DevBuf d_state, d_F, d_D, d_jobs, d_msgs, d_pool;
+    std::vector<FramerState> h_state;
+    std::vector<FramerMsg> h_msgs;
+    std::vector<unsigned char> h_pool;
+    bool fetched = false;
+};
+
+int grhip_framer_sink_1_batch_create(grhip_framer_sink_1_batch **h, int n_streams, size_t max_items_per_stream, int device)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    if (n_streams < 1 || max_items_per_stream < 1 || max_items_per_stream >= (1ull << 31))
+        return fail(GRHIP_EINVAL, "framer_sink_1_batch: bad stream count / capture length");
+    auto *b = new (std::nothrow) grhip_framer_sink_1_batch();
+    if (!b) return fail(GRHIP_ENOMEM, "alloc");
+    b->S = n_streams;
+    b->max_items = (long long)max_items_per_stream;
+    b->words_stride = ((b->max_items + 31) >> 5) + 2;            // two zero words behind every stream
+    b->rec_stride = b->max_items / 32 + 8;                        // a packet costs at least 32 items
+    b->pool_stride = ((b->max_items / 8 + 4096 + 16 + 15) / 16) * 16;
+    const size_t S = (size_t)n_streams;
+    int rc = b->init_device(device);
+    if (!rc) rc = b->d_state.reserve(S * sizeof(FramerState));
+    if (!rc) rc = b->d_F.reserve(S * b->words_stride * 4);
+    if (!rc) rc = b->d_D.reserve(S * b->words_stride * 4);
+    if (!rc) rc = b->d_jobs.reserve(S * b->rec_stride * sizeof(FramerJob));
+    if (!rc) rc = b->d_msgs.reserve(S * b->rec_stride * sizeof(FramerMsg));
+    if (!rc) rc = b->d_pool.reserve(S * b->pool_stride);
+    if (rc) { grhip_framer_sink_1_batch_destroy(b); return rc; }
+    *h = b;
+    return GRHIP_OK;
+}
+
+void grhip_framer_sink_1_batch_destroy(grhip_framer_sink_1_batch *h)
+{
+    if (!h) return;
+    (void)h->bind();
+    h->d_state.release(); h->d_F.release(); h->d_D.release(); h->d_jobs.release(); h->d_msgs.release(); h->d_pool.release();
+    h->destroy_base();
+    delete h;
+}
+
+int grhip_framer_sink_1_batch_run_device(grhip_framer_sink_1_batch *h, const unsigned char *d_in, size_t stream_stride_items,
+                                         const int *d_nitems, int nitems_stride, size_t n_items_max, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (!d_in) return fail(GRHIP_EINVAL, "null buffer");
+    if ((long long)n_items_max > h->max_items) return fail(GRHIP_EINVAL, "n_items_max exceeds max_items_per_stream");
+    int rc = h->bind();
+    if (rc) return rc;
+    hipStream_t st = h->pick(stream);
+    h->fetched = false;
+    if (n_items_max == 0) { GRHIP_HIP(hipMemsetAsync(h->d_state.p, 0, (size_t)h->S * sizeof(FramerState), st)); return GRHIP_OK; }
+    const unsigned pack_blocks = (unsigned)std::min<long long>((h->words_stride + 255) / 256, 1024);
+    hipLaunchKernelGGL(framer_pack_batch_kernel, dim3(pack_blocks, (unsigned)h->S), dim3(256), 0, st, d_in, (long long)stream_stride_items,
+                       d_nitems, nitems_stride, (long long)n_items_max, h->d_F.as<unsigned>(), h->d_D.as<unsigned>(), h->words_stride);
+    hipLaunchKernelGGL(framer_walk_batch_kernel, dim3((unsigned)h->S), dim3(64), 0, st, h->d_F.as<unsigned>(), h->d_D.as<unsigned>(),
+                       h->words_stride, d_nitems, nitems_stride, (long long)n_items_max, h->d_state.as<FramerState>(),
+                       h->d_msgs.as<FramerMsg>(), h->d_jobs.as<FramerJob>(), h->rec_stride);
+    const unsigned pay_blocks = (unsigned)std::min<long long>((long long)n_items_max / 4096 + 1, 64);
+    hipLaunchKernelGGL(framer_payload_batch_kernel, dim3(pay_blocks, (unsigned)h->S), dim3(256), 0, st, h->d_D.as<unsigned>(),
+                       h->words_stride, h->d_state.as<FramerState>(), h->d_jobs.as<FramerJob>(), h->rec_stride,
+                       h->d_pool.as<unsigned char>(), h->pool_stride);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+int grhip_framer_sink_1_batch_fetch(grhip_framer_sink_1_batch *h, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    int rc = h->bind();
+    if (rc) return rc;
+    hipStream_t st = h->pick(stream);
+    const size_t S = (size_t)h->S;
+    h->h_state.resize(S);
+    GRHIP_HIP(hipMemcpyAsync(h->h_state.data(), h->d_state.p, S * sizeof(FramerState), hipMemcpyDeviceToHost, st));
+    GRHIP_HIP(hipStreamSynchronize(st));
+    h->h_msgs.assign(S * (size_t)h->rec_stride, FramerMsg{});
+    h->h_pool.assign(S * (size_t)h->pool_stride, 0);
+    long long total = 0;
+    for (size_t s = 0; s < S; ++s) {
+        const FramerState &fs = h->h_state[s];
+        if (!fs.msg_count) continue;
+        total += fs.msg_count;
+        GRHIP_HIP(hipMemcpyAsync(h->h_msgs.data() + s * h->rec_stride, h->d_msgs.as<FramerMsg>() + s * h->rec_stride,
+                                 (size_t)fs.msg_count * sizeof(FramerMsg), hipMemcpyDeviceToHost, st));
+        if (fs.pool_used)
+            GRHIP_HIP(hipMemcpyAsync(h->h_pool.data() + s * h->pool_stride, h->d_pool.as<unsigned char>() + s * h->pool_stride,
+                                     std::min<size_t>(fs.pool_used, (size_t)h->pool_stride), hipMemcpyDeviceToHost, st));
+    }
+    GRHIP_HIP(hipStreamSynchronize(st));
+    h->fetched = true;
+    return (int)std::min<long long>(total, 0x7ffffffe);
+}
+
+int grhip_framer_sink_1_batch_count(grhip_framer_sink_1_batch *h, int stream_index)
+{
+    if (!h || !h->fetched) return fail(GRHIP_EINVAL, "framer_sink_1_batch: call fetch first");
+    if (stream_index < 0 || stream_index >= h->S) return fail(GRHIP_EINVAL, "stream index out of range");
+    return (int)h->h_state[(size_t)stream_index].msg_count;
+}
+
+int grhip_framer_sink_1_batch_get(grhip_framer_sink_1_batch *h, int stream_index, int msg_index, int *whitener_offset,
+                                  unsigned char *payload, int capacity)
+{
+    if (!h || !h->fetched) return fail(GRHIP_EINVAL, "framer_sink_1_batch: call fetch first");
+    if (stream_index < 0 || stream_index >= h->S) return fail(GRHIP_EINVAL, "stream index out of range");
+    const FramerState &fs = h->h_state[(size_t)stream_index];
+    if (msg_index < 0 || (unsigned)msg_index >= fs.msg_count) return fail(GRHIP_EINVAL, "message index out of range");
+    const FramerMsg &m = h->h_msgs[(size_t)stream_index * h->rec_stride + (size_t)msg_index];
+    if ((int)m.len > capacity || (m.len && !payload)) return fail(GRHIP_EINVAL, "payload buffer too small (4096 always fits)");
+    if (whitener_offset) *whitener_offset = (int)m.woff;
+    if (m.len) memcpy(payload, h->h_pool.data() + (size_t)stream_index * h->pool_stride + m.off, m.len);
+    return (int)m.len;
 }
 
 int grhip_framer_sink_1_work(grhip_framer_sink_1 *h, int noutput_items, const unsigned char *in)

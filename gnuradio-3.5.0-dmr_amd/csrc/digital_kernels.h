@@ -24,7 +24,11 @@ int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items
 int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipStream_t st);
 // pager_slicer_fb: d_avg[s] carried in device memory; streams s at in + s*in_stride / out + s*out_stride
 int launch_pager_slicer(float *d_avg, int n_streams, float alpha, float beta, const float *in, long long in_stride,
-                        unsigned char *out, long long out_stride, long long n, hipStream_t st);
+                        unsigned char *out, long long out_stride, long long n, hipStream_t st, const int *n_ptr = nullptr,
+                        int n_ptr_stride = 0);
+int launch_unpack_k_bits_streams(unsigned k, int n_streams, const unsigned char *in, long long in_stride, unsigned char *out,
+                                 long long out_stride, long long n_in_max, const int *n_ptr, int n_ptr_stride, int *n_out,
+                                 int n_out_stride, hipStream_t st);
 // gr_stream_to_streams (split = true) / gr_streams_to_stream (split = false): stream j of `multi` starts at
 // multi + j * multi_stride_items items
 int launch_streams(bool split, void *single, void *multi, long long multi_stride_items, int nstreams, size_t item_size,

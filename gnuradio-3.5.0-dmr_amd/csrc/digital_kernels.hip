@@ -180,10 +180,15 @@ constexpr int PS_CH = 1024;
 
 __global__ void __launch_bounds__(64)
 pager_slicer_kernel(float *__restrict__ d_avg, float alpha, float beta, const float *__restrict__ in,
-                    long long in_stride, unsigned char *__restrict__ out, long long out_stride, long long n)
+                    long long in_stride, unsigned char *__restrict__ out, long long out_stride, long long n,
+                    const int *__restrict__ n_ptr, int n_ptr_stride)
 {
     __shared__ float s_x[PS_CH], s_t[PS_CH];
     const int s = blockIdx.x, lane = threadIdx.x;
+    if (n_ptr) {
+        const long long m = n_ptr[(long long)s * n_ptr_stride];
+        n = m < n ? (m < 0 ? 0 : m) : n;
+    }
     const float *__restrict__ x = in + (long long)s * in_stride;
     unsigned char *__restrict__ y = out + (long long)s * out_stride;
     float avg = d_avg[s];
@@ -223,11 +228,12 @@ pager_slicer_kernel(float *__restrict__ d_avg, float alpha, float beta, const fl
 }
 
 int launch_pager_slicer(float *d_avg, int n_streams, float alpha, float beta, const float *in, long long in_stride,
-                        unsigned char *out, long long out_stride, long long n, hipStream_t st)
+                        unsigned char *out, long long out_stride, long long n, hipStream_t st, const int *n_ptr,
+                        int n_ptr_stride)
 {
     if (n <= 0 || n_streams <= 0) return GRHIP_OK;
     hipLaunchKernelGGL(pager_slicer_kernel, dim3(n_streams), dim3(64), 0, st, d_avg, alpha, beta, in, in_stride, out,
-                       out_stride, n);
+                       out_stride, n, n_ptr, n_ptr_stride);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
 }
@@ -246,6 +252,43 @@ unpack_k_bits_kernel(unsigned k, const unsigned char *__restrict__ in, unsigned 
         const unsigned j = k - 1 - (unsigned)(i - q * k);
         out[i] = (unsigned char)(((unsigned)in[q] >> j) & 1u);
     }
+}
+
+// multi-capture form: blockIdx.y = stream; stream s has n_ptr[s * n_ptr_stride] input items (at most n_in_max) and
+// gets k times as many output items, whose number goes to n_out[s * n_out_stride]
+__global__ void __launch_bounds__(256)
+unpack_k_bits_streams_kernel(unsigned k, const unsigned char *__restrict__ in, long long in_stride, unsigned char *__restrict__ out,
+                             long long out_stride, long long n_in_max, const int *__restrict__ n_ptr, int n_ptr_stride,
+                             int *__restrict__ n_out, int n_out_stride)
+{
+    const int s = blockIdx.y;
+    long long n_in = n_in_max;
+    if (n_ptr) {
+        const long long m = n_ptr[(long long)s * n_ptr_stride];
+        n_in = m < n_in ? (m < 0 ? 0 : m) : n_in;
+    }
+    const long long n = n_in * k;
+    const unsigned char *__restrict__ x = in + (long long)s * in_stride;
+    unsigned char *__restrict__ y = out + (long long)s * out_stride;
+    if (n_out && blockIdx.x == 0 && threadIdx.x == 0) n_out[(long long)s * n_out_stride] = (int)n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long q = i / k;
+        const unsigned j = k - 1 - (unsigned)(i - q * k);
+        y[i] = (unsigned char)(((unsigned)x[q] >> j) & 1u);
+    }
+}
+
+int launch_unpack_k_bits_streams(unsigned k, int n_streams, const unsigned char *in, long long in_stride, unsigned char *out,
+                                 long long out_stride, long long n_in_max, const int *n_ptr, int n_ptr_stride, int *n_out,
+                                 int n_out_stride, hipStream_t st)
+{
+    if (n_streams <= 0 || n_in_max <= 0) return GRHIP_OK;
+    long long blocks = (n_in_max * k + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(unpack_k_bits_streams_kernel, dim3((unsigned)blocks, (unsigned)n_streams), dim3(256), 0, st, k, in, in_stride, out,
+                       out_stride, n_in_max, n_ptr, n_ptr_stride, n_out, n_out_stride);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
 }
 
 int launch_unpack_k_bits(unsigned k, const unsigned char *in, unsigned char *out, long long noutput_items, hipStream_t st)

@@ -384,6 +384,27 @@ GRHIP_API int grhip_framer_sink_1_pop(grhip_framer_sink_1 *h, int *whitener_offs
 GRHIP_API int grhip_framer_sink_1_drain(grhip_framer_sink_1 *h, int max_msgs, int *whitener_offsets, int *lengths,
                                         unsigned char *payload, size_t payload_capacity);
 
+/* Multi-capture entry of gr_framer_sink_1 (same reference, general/gr_framer_sink_1.cc:90-190): n_streams
+ * independent item streams framed by one call, one wavefront per stream, every stream from the search
+ * state (a capture is framed whole, as the chain processes it; a packet cut off by the end of the
+ * capture is dropped, as the reference drops it when the flowgraph ends).  Stream s is at
+ * d_in + s * stream_stride_items and holds min(n_items_max, d_nitems[s * nitems_stride]) items (d_nitems,
+ * a device array, may be NULL: n_items_max each) -- e.g. the d_bits / d_nbits of grhip_dmr_chain.
+ *   run_device  enqueues on `stream`, no synchronisation;
+ *   fetch       waits for it, brings every stream's messages to the host, returns their total number;
+ *   count/get   messages of one stream, in order: get returns the payload length (0..4095), stores arg1. */
+typedef struct grhip_framer_sink_1_batch grhip_framer_sink_1_batch;
+GRHIP_API int grhip_framer_sink_1_batch_create(grhip_framer_sink_1_batch **h, int n_streams, size_t max_items_per_stream,
+                                               int device);
+GRHIP_API void grhip_framer_sink_1_batch_destroy(grhip_framer_sink_1_batch *h);
+GRHIP_API int grhip_framer_sink_1_batch_run_device(grhip_framer_sink_1_batch *h, const unsigned char *d_in,
+                                                   size_t stream_stride_items, const int *d_nitems, int nitems_stride,
+                                                   size_t n_items_max, void *stream);
+GRHIP_API int grhip_framer_sink_1_batch_fetch(grhip_framer_sink_1_batch *h, void *stream);
+GRHIP_API int grhip_framer_sink_1_batch_count(grhip_framer_sink_1_batch *h, int stream_index);
+GRHIP_API int grhip_framer_sink_1_batch_get(grhip_framer_sink_1_batch *h, int stream_index, int msg_index,
+                                            int *whitener_offset, unsigned char *payload, int capacity);
+
 /* ======================================================================
  * gr_stream_to_streams / gr_streams_to_stream  (the adapters either side of the
  * channeliser)
@@ -528,6 +549,13 @@ GRHIP_API void grhip_dmr_chain_destroy(grhip_dmr_chain *h);
  * stream at a time): the whole chain is then bit-exact against the reference's
  * generic path, symbols and bit decisions included. */
 GRHIP_API int grhip_dmr_chain_set_mode(grhip_dmr_chain *h, int mode);
+/* 4FSK tail: with enable != 0 the symbols go through pager_slicer_fb(alpha)
+ * (gr-pager/lib/pager_slicer_fb.cc:47-84) -> gr_unpack_k_bits_bb(2) (general/gr_unpack_k_bits_bb.cc:64-69) ->
+ * the access-code correlator instead of the binary slicer: both bits of every symbol, most significant first.
+ * d_bits then receives TWO items per symbol (bits_stride >= 2 * n_samples / decimation) and d_nbits their
+ * number per stream.  The access code is matched against that dibit stream (gr-digital/python/pkt.py:143-147
+ * feeds the correlator unpacked bits in the same way). */
+GRHIP_API int grhip_dmr_chain_set_four_level(grhip_dmr_chain *h, int enable, float pager_alpha);
 /* d_in: n_streams captures of n_samples complex each, stream s at
  * d_in + s*stream_stride_items (NO history in front: the chain supplies the
  * zeros a fresh flowgraph would).  d_bits: n_streams * bits_stride bytes;
@@ -536,8 +564,8 @@ GRHIP_API int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, s
                                          size_t stream_stride_items, unsigned char *d_bits,
                                          size_t bits_stride, int *d_nbits, void *stream);
 /* intermediate products of the last run (device pointers owned by the handle):
- * which: 0 demod floats, 1 M&M soft symbols; *stride receives the per-stream
- * stride in items */
+ * which: 0 demod floats, 1 M&M soft symbols, 2 pager_slicer symbols (bytes, 4FSK tail only);
+ * *stride receives the per-stream stride in items */
 GRHIP_API int grhip_dmr_chain_intermediate(grhip_dmr_chain *h, int which, void **d_ptr, size_t *stride);
 
 /* ---- small device-memory helpers for hosts without a HIP binding -------- */

@@ -129,3 +129,86 @@ def test_chain_properties_full_size(gpu, wl):
     ch.run_device(d_in, n, n, d_bits, nout, d_n, st)
     st.synchronize()
     assert np.array_equal(d_bits.cpu().numpy()[0, :nb[0]], first)   # idempotent
+
+
+def test_four_level_tail_in_the_batched_chain(gpu, po, wl):
+    """pager_slicer_fb -> unpack_k_bits(2) -> correlate_access_code inside the multi-capture chain
+    (S > 1, per-stream symbol counts), then the multi-capture framer_sink_1 on its output.  GENERIC mode: every
+    stage bit-exact against the oracle chain; FAST mode: the tail is exact given the symbols the chain produced."""
+    import ctypes
+    torch = _torch()
+    S, n = 3, 400_000
+    alpha = 0.002
+    xs = [wl.fsk4_capture(n, stream_id=70 + s) for s in range(S)]
+    dev = torch.device("cuda", 0)
+    stride = n + 64
+    d_in = torch.zeros((S, stride, 2), dtype=torch.float32, device=dev)
+    for s in range(S):
+        d_in[s, :n] = torch.from_numpy(xs[s].view(np.float32).reshape(-1, 2))
+    nout = n // 4
+    d_bits = torch.zeros((S, 2 * nout), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    ch = _make_chain(gpu, wl, S, n)
+    ch.set_four_level(True, alpha)
+    fr = gpu.framer_sink_1_batch(S, 2 * nout)
+    st = torch.cuda.Stream(device=dev)
+    code, thr = wl.access_code_string(), wl.CFG4["threshold"]
+    for mode in (gpu.MODE_FAST, gpu.MODE_GENERIC):
+        ch.set_mode(mode)
+        ch.run_device(d_in, n, stride, d_bits, 2 * nout, d_n, st)
+        fr.run_device(d_bits, 2 * nout, d_n, 2 * nout, st)
+        msgs = fr.messages(st)
+        nb = d_n.cpu().numpy()
+        bits = d_bits.cpu().numpy()
+        p_soft, s_soft = ch.intermediate(1)
+        p_sym, s_sym = ch.intermediate(2)
+        for s in range(S):
+            dem_ref, soft_ref, _ = _oracle_chain(po, wl, xs[s])
+            nsym = int(nb[s]) // 2
+            assert nb[s] == 2 * nsym and nsym == len(soft_ref)
+            soft = np.empty(nsym, np.float32)
+            gpu.lib().grhip_memcpy_d2h(soft.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_soft + 4 * s * s_soft), nsym * 4)
+            sym = np.empty(nsym, np.uint8)
+            gpu.lib().grhip_memcpy_d2h(sym.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_sym + s * s_sym), nsym)
+            src = soft_ref if mode == gpu.MODE_GENERIC else soft          # FAST: exact given its own symbols
+            if mode == gpu.MODE_GENERIC:
+                assert bits_equal(soft, soft_ref)
+            o_sym = po.PagerSlicer(alpha).work(src)
+            o_bits = po.unpack_k_bits_bb(2, o_sym)
+            o_out = po.CorrelateAccessCode(code, thr).work(o_bits)
+            assert np.array_equal(sym, o_sym)
+            assert np.array_equal(bits[s, :nb[s]], o_out)
+            assert msgs[s] == po.FramerSink1().work(o_out)
+            if mode == gpu.MODE_FAST:
+                # against the reference's own symbols: decisions differ only where a soft symbol sits on a threshold
+                r_sym = po.PagerSlicer(alpha).work(soft_ref)
+                assert (r_sym != sym).mean() <= 1e-4
+
+
+def test_framer_batch_matches_oracle_per_stream(gpu, po):
+    """multi-capture framer_sink_1: streams of different lengths (device-side counts), packets of every size,
+    bad headers, stray flags; each stream framed from the search state, equal to the oracle stream by stream"""
+    torch = _torch()
+    from test_gpu_framer import make_stream
+    rng = np.random.default_rng(5)
+    lens = [150_001, 31, 0, 70_000, 4096, 99_999, 1]
+    S, stride = len(lens), 150_016
+    xs = [make_stream(rng, L, gap=(50, 10, 1, 3000, 100, 1, 1)[i], maxlen=(90, 0, 0, 700, 4095, 3, 0)[i]) for i, L in enumerate(lens)]
+    dev = torch.device("cuda", 0)
+    d_in = torch.zeros((S, stride), dtype=torch.uint8, device=dev)
+    for s in range(S):
+        d_in[s, :lens[s]] = torch.from_numpy(xs[s])
+    d_n = torch.tensor(lens, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    fr = gpu.framer_sink_1_batch(S, stride)
+    for rep in range(2):            # every run starts from the search state
+        fr.run_device(d_in, stride, d_n, stride, st)
+        got = fr.messages(st)
+        for s in range(S):
+            assert got[s] == po.FramerSink1().work(xs[s]), s
+    assert sum(len(m) for m in got) > 1000
+    # without a count array every stream has n_items_max items
+    fr.run_device(d_in, stride, None, 4096, st)
+    got = fr.messages(st)
+    for s in range(S):
+        assert got[s] == po.FramerSink1().work(np.concatenate([xs[s], np.zeros(stride, np.uint8)])[:4096]), s
