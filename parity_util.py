@@ -11,6 +11,33 @@ ATAN_STEP = 0.0039215689 - 0.0019765894
 CFG2_GAIN = 2.5e6 / (2.0 * np.pi * 33750.0)
 
 
+def demod_report(got, ref, skip=64, tol=1e-5, gain=CFG2_GAIN):
+    """The numbers behind demod_close, for reporting (smoke(), tests): a dict with
+      steady_rel_inf    max |got - ref| / max|ref| after the start-up transient, step-exempted samples removed
+      per_element_rel   max |got - ref| / |ref| over the steady samples with |ref| > 0.1 max|ref| (same removal)
+      step_exempted     samples that differ by the reference's own arctangent step at z = 1/255
+      transient_rel_inf max |got - ref| / max|ref| inside the first `skip` outputs
+      ok                the demod_close verdict"""
+    got = np.asarray(got); ref = np.asarray(ref)
+    ok, worst = demod_close(got, ref, skip, tol, gain)
+    rep = {"ok": bool(ok), "steady_rel_inf": float(worst), "per_element_rel": 0.0, "step_exempted": 0,
+           "transient_rel_inf": 0.0}
+    if got.shape != ref.shape or len(ref) <= skip:
+        return rep
+    full = float(np.abs(ref).max())
+    g = got[skip:].astype(np.float64); r = ref[skip:].astype(np.float64)
+    err = np.abs(g - r)
+    step = abs(gain) * ATAN_STEP
+    at_step = (err > tol * float(np.abs(r).max())) & (np.abs(err - step) <= 0.02 * step)
+    rep["step_exempted"] = int(at_step.sum())
+    keep = ~at_step
+    big = keep & (np.abs(r) > 0.1 * float(np.abs(r).max()))
+    if big.any():
+        rep["per_element_rel"] = float((err[big] / np.abs(r[big])).max())
+    rep["transient_rel_inf"] = float(np.abs(got[:skip].astype(np.float64) - ref[:skip]).max() / max(full, 1e-30))
+    return rep
+
+
 def demod_close(got, ref, skip=64, tol=1e-5, gain=CFG2_GAIN):
     """Tolerance check for quadrature-demod outputs of the FAST path.
 

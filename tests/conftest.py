@@ -61,4 +61,4 @@ def bits_equal(a, b):
     return bool(np.array_equal(a.view(np.uint8), b.view(np.uint8)))
 
 
-from parity_util import demod_close  # noqa: E402,F401  (shared with __graft_entry__.smoke)
+from parity_util import demod_close, demod_report  # noqa: E402,F401  (shared with __graft_entry__.smoke)

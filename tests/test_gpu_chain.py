@@ -95,6 +95,13 @@ def test_chain_three_streams_vs_oracle(gpu, po, wl):
                 assert np.all(np.abs(soft_ref[flips]) < 1e-2) and flips.sum() <= 8
                 # every planted sync word is still found (threshold 4 absorbs a stray flip)
                 assert abs(int((bits[s, :nb[s]] & 2).sum()) - int((out_ref & 2).sum())) <= 1
+                # ... and at the SAME symbol index as in the reference: the flag positions of the
+                # two outputs coincide, except a flag the reference itself raises only because of a flipped bit
+                mine_pos = np.nonzero(bits[s, :nb[s]] & 2)[0]
+                ref_pos = np.nonzero(out_ref & 2)[0]
+                planted = ref_pos[np.isin(ref_pos, mine_pos)]
+                assert len(planted) >= len(ref_pos) - 1 and len(planted) >= len(mine_pos) - 1
+                assert len(ref_pos) >= 5
             assert (out_ref & 2).sum() >= n // 4 // 10 // wl.CFG4["sync_period_syms"]     # sync words found
 
 

@@ -5,7 +5,7 @@ CPU oracle.  Tolerances: GENERIC mode bit-exact; FAST mode 1e-5 relative
 import numpy as np
 import pytest
 
-from conftest import bits_equal, demod_close, rel_err_max
+from conftest import bits_equal, demod_close, demod_report, rel_err_max
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -560,3 +560,29 @@ def test_set_taps_does_not_tear_a_launch_in_flight(gpu, po):
     got_new = d_y2.cpu().numpy().reshape(-1).view(np.complex64)
     assert bits_equal(got_old, po.fir_ccf(t_old, x, n, decim))
     assert bits_equal(got_new, po.fir_ccf(t_new, x, n, decim))
+
+
+@pytest.mark.parametrize("mode_name", ["MODE_FAST", "MODE_FAST_VALU"])
+def test_fast_demod_parity_numbers_cfg2(gpu, po, wl, mode_name, capsys):
+    """the FAST demodulator's error is reported the way it is for the xlating output --
+    per element where |ref| is not tiny -- next to the infinity-norm figure, the count of samples that sit on
+    the reference's own arctangent step and the transient maximum (parity_util.demod_report)."""
+    c = wl.CFG2
+    n = 2_000_000
+    x = wl.fsk4_capture(n, stream_id=11)
+    proto = wl.cfg2_proto_taps()
+    nout = n // c["decim"]
+    ref = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], x)
+    blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
+    blk.set_mode(getattr(gpu, mode_name))
+    rep = demod_report(blk.work(nout, wl.with_history(x, 255)), ref, gain=c["demod_gain"])
+    with capsys.disabled():
+        print("\n[%s] cfg2 demod parity: %s" % (mode_name, rep))
+    assert rep["ok"]
+    assert rep["steady_rel_inf"] <= 1e-5
+    # per element over |ref| > 0.1 max|ref|: an angle is as accurate as |dy| / |y| of the FIR output under it,
+    # which at 1e-6 (FIR) and |ref| down to a tenth of full scale bounds this at ~1e-5 x 10 in the worst
+    # case; measured: see the printed figure
+    assert rep["per_element_rel"] <= 3e-5
+    assert rep["step_exempted"] <= max(2, int(2e-5 * nout))
+    assert rep["transient_rel_inf"] <= 1e-2
