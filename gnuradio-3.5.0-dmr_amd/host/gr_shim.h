@@ -8,11 +8,19 @@
 //   gr_sync_interpolator gnuradio-core/src/lib/runtime/gr_sync_interpolator.cc:30-75
 //   gr_io_signature     gnuradio-core/src/lib/runtime/gr_io_signature.h
 //   gr_message / gr_msg_queue  gnuradio-core/src/lib/runtime/gr_message.h:36-81, gr_msg_queue.h:36-86
+//   gr_fir_{ccf,fff,ccc}, gr_fir_XXX_info   gnuradio-core/src/lib/filter/gr_fir_XXX.h.t:48-122,
+//                                           filter/generate_gr_fir_util.py:25-32 (the kernel-level seam)
+//   gr_fft_vcc (abstract base)              gnuradio-core/src/lib/general/gr_fft_vcc.h:41-59, gr_fft_vcc.cc:40-64
 // When building against a real GNU Radio 3.5 tree define GRHIP_USE_GNURADIO and
 // the real headers are used instead (the wrappers only rely on what is here).
 #pragma once
 
 #ifdef GRHIP_USE_GNURADIO
+#include <gr_fft_vcc.h>
+#include <gr_fir_ccc.h>
+#include <gr_fir_ccf.h>
+#include <gr_fir_fff.h>
+#include <gr_fir_util.h>
 #include <gr_block.h>
 #include <gr_io_signature.h>
 #include <gr_message.h>
@@ -233,5 +241,55 @@ public:
 };
 typedef boost::shared_ptr<gr_msg_queue> gr_msg_queue_sptr;
 inline gr_msg_queue_sptr gr_make_msg_queue(unsigned limit = 0) { return gr_msg_queue_sptr(new gr_msg_queue(limit)); }
+
+
+// ---- kernel-level FIR seam: abstract gr_fir_XXX (filter/gr_fir_XXX.h.t:48-122) -------------------
+template <class T> inline std::vector<T> gr_reverse(const std::vector<T> &v) { return std::vector<T>(v.rbegin(), v.rend()); }
+
+#define GRHIP_SHIM_FIR(NAME, I, O, TAP)                                                                     \
+    class NAME {                                                                                            \
+    protected:                                                                                              \
+        std::vector<TAP> d_taps; /* reversed taps */                                                        \
+    public:                                                                                                 \
+        NAME() {}                                                                                           \
+        NAME(const std::vector<TAP> &taps) : d_taps(gr_reverse(taps)) {}                                    \
+        virtual ~NAME() {}                                                                                  \
+        virtual O filter(const I input[]) = 0;                                                              \
+        virtual void filterN(O output[], const I input[], unsigned long n) = 0;                             \
+        virtual void filterNdec(O output[], const I input[], unsigned long n, unsigned decimate) = 0;       \
+        virtual void set_taps(const std::vector<TAP> &taps) { d_taps = gr_reverse(taps); }                  \
+        unsigned ntaps() const { return d_taps.size(); }                                                    \
+        virtual const std::vector<TAP> get_taps() const { return gr_reverse(d_taps); }                      \
+    };                                                                                                      \
+    struct NAME##_info {                                                                                    \
+        const char *name; /* implementation name, e.g. "generic", "SSE" */                                  \
+        NAME *(*create)(const std::vector<TAP> &taps);                                                      \
+    };
+GRHIP_SHIM_FIR(gr_fir_ccf, gr_complex, gr_complex, float)
+GRHIP_SHIM_FIR(gr_fir_fff, float, float, float)
+GRHIP_SHIM_FIR(gr_fir_ccc, gr_complex, gr_complex, gr_complex)
+
+// ---- gr_fft_vcc: the abstract base that holds size / window / direction (general/gr_fft_vcc.h:41-59) ----
+class gr_fft_vcc : public gr_sync_block {
+protected:
+    unsigned int d_fft_size;
+    std::vector<float> d_window;
+    bool d_forward;
+    bool d_shift;
+    gr_fft_vcc(const std::string &name, int fft_size, bool forward, const std::vector<float> &window, bool shift)
+        : gr_sync_block(name, gr_make_io_signature(1, 1, fft_size * sizeof(gr_complex)),
+                        gr_make_io_signature(1, 1, fft_size * sizeof(gr_complex))),
+          d_fft_size(fft_size), d_forward(forward), d_shift(shift)
+    {
+        set_window(window);
+    }
+public:
+    ~gr_fft_vcc() {}
+    bool set_window(const std::vector<float> &window)          // gr_fft_vcc.cc:55-64
+    {
+        if (window.size() == 0 || window.size() == d_fft_size) { d_window = window; return true; }
+        return false;
+    }
+};
 
 #endif  // GRHIP_USE_GNURADIO

@@ -9,7 +9,7 @@
 //   grhip_clock_recovery_mm_ff               <- digital_clock_recovery_mm_ff (gr-digital/include/...h:44-92)
 //   grhip_binary_slicer_fb                   <- digital_binary_slicer_fb
 //   grhip_correlate_access_code_bb           <- digital_correlate_access_code_bb
-//   grhip_fft_vcc                            <- gr_fft_vcc (general/gr_fft_vcc.h:41-59)
+//   gr_fft_vcc_hip (grhip_make_fft_vcc)       <- gr_fft_vcc_fftw, on the abstract gr_fft_vcc base (general/gr_fft_vcc.h:41-59)
 //   grhip_pfb_channelizer_ccf                <- gr_pfb_channelizer_ccf (filter/gr_pfb_channelizer_ccf.h:115-178)
 //
 // output_multiple is the REFERENCE's for every block (1; nsamples for fft_filter_ccc; the
@@ -438,33 +438,48 @@ inline grhip_correlate_access_code_bb_sptr grhip_make_correlate_access_code_bb(c
 }
 
 // ---------------------------------------------------------------------------
-// gr_fft_vcc  (items are vectors of fft_size complex)
+// gr_fft_vcc_hip: sits where gr_fft_vcc_fftw sits (general/gr_fft_vcc_fftw.h:36-58).  The base class owns size, window,
+// direction and shift; its set_window() is not virtual and only stores the vector, so work() hands a changed
+// window to the device before it transforms (the FFTW subclass reads d_window in work() too, .cc:68-76).
 // ---------------------------------------------------------------------------
-class grhip_fft_vcc_blk;
-typedef boost::shared_ptr<grhip_fft_vcc_blk> grhip_fft_vcc_sptr;
-class grhip_fft_vcc_blk : public gr_sync_block {
+class gr_fft_vcc_hip;
+typedef boost::shared_ptr<gr_fft_vcc_hip> gr_fft_vcc_hip_sptr;
+class gr_fft_vcc_hip : public gr_fft_vcc {
     grhip_fft_vcc *d_h = nullptr;
-    grhip_fft_vcc_blk(int fft_size, bool forward, const std::vector<float> &window, bool shift, int device)
-        : gr_sync_block("fft_vcc_hip", gr_make_io_signature(1, 1, fft_size * sizeof(gr_complex)),
-                        gr_make_io_signature(1, 1, fft_size * sizeof(gr_complex)))
+    std::vector<float> d_sent;
+    gr_fft_vcc_hip(int fft_size, bool forward, const std::vector<float> &window, bool shift, int device)
+        : gr_fft_vcc("fft_vcc_hip", fft_size, forward, window, shift), d_sent(d_window)
     {
-        grhip_detail::check(grhip_fft_vcc_create(&d_h, fft_size, forward, window.data(), window.size(), shift, device));
+        grhip_detail::check(grhip_fft_vcc_create(&d_h, fft_size, forward, d_window.data(), d_window.size(), shift, device));
     }
-    friend grhip_fft_vcc_sptr grhip_make_fft_vcc(int, bool, const std::vector<float> &, bool, int);
+    friend gr_fft_vcc_hip_sptr gr_make_fft_vcc_hip(int, bool, const std::vector<float> &, bool, int);
 public:
-    ~grhip_fft_vcc_blk() { grhip_fft_vcc_destroy(d_h); }
-    bool set_window(const std::vector<float> &w) { return grhip_fft_vcc_set_window(d_h, w.data(), w.size()) == 1; }
-    int work(int n, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    ~gr_fft_vcc_hip() { grhip_fft_vcc_destroy(d_h); }
+    int work(int noutput_items, gr_vector_const_void_star &in, gr_vector_void_star &out) override
     {
-        int r = grhip_fft_vcc_work(d_h, n, in[0], out[0]);
+        if (d_window != d_sent) {
+            grhip_detail::check(grhip_fft_vcc_set_window(d_h, d_window.data(), d_window.size()));
+            d_sent = d_window;
+        }
+        int r = grhip_fft_vcc_work(d_h, noutput_items, in[0], out[0]);
         grhip_detail::check(r);
         return r;
     }
 };
+inline gr_fft_vcc_hip_sptr gr_make_fft_vcc_hip(int fft_size, bool forward, const std::vector<float> &window,
+                                               bool shift = false, int device = 0)
+{
+    if (fft_size <= 0) throw std::out_of_range("gr_fft_vcc_hip: invalid fft_size");      // gri_fft.cc:104-105
+    return gnuradio::get_initial_sptr(new gr_fft_vcc_hip(fft_size, forward, window, shift, device));
+}
+
+// the block-level factory of round 1 keeps its name
+typedef gr_fft_vcc_hip grhip_fft_vcc_blk;
+typedef gr_fft_vcc_hip_sptr grhip_fft_vcc_sptr;
 inline grhip_fft_vcc_sptr grhip_make_fft_vcc(int fft_size, bool forward, const std::vector<float> &window,
                                              bool shift = false, int device = 0)
 {
-    return gnuradio::get_initial_sptr(new grhip_fft_vcc_blk(fft_size, forward, window, shift, device));
+    return gr_make_fft_vcc_hip(fft_size, forward, window, shift, device);
 }
 
 // ---------------------------------------------------------------------------

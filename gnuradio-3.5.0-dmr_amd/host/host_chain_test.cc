@@ -12,7 +12,7 @@
 #include <iostream>
 #include <string>
 
-#include "grhip_blocks.h"
+#include "grhip_fir_kernels.h"
 #include "grhip_executor.h"
 
 template <class T> static std::vector<T> slurp(const std::string &p)
@@ -54,11 +54,175 @@ static int test_errors()
     return fails;
 }
 
+// ---- "for each implementation in the info table" (the pattern of filter/qa_gr_fir_ccf.cc:103-177) ----------
+// Every registered implementation is run on integer-valued pseudo-random data for ntaps in [0, 9] and output
+// lengths in [0, 17] against a plain dot product in double; tolerance |expected| * 1e-5 as in the reference
+// (qa_gr_fir_ccf.cc:54,151-152).  With the real GNU Radio the table also holds "generic" and "SSE"; here it holds
+// what grhip_fir_sysconfig adds.
+// the reference's generators: srandom(0), rint(uniform() * 32767) (qa_gr_fir_ccf.cc:63-85; 32768 for fff,
+// qa_gr_fir_fff.cc:120-131) -- glibc's random() gives the very sequence the reference's own run uses
+static float qa_uniform() { return 2.0 * ((float)random() / 2147483647.0 - 0.5); }
+template <class T> static T rnd_item(float scale);
+template <> float rnd_item<float>(float scale) { return (float)rint(qa_uniform() * scale); }
+template <> gr_complex rnd_item<gr_complex>(float scale)
+{
+    const float re = rint(qa_uniform() * scale), im = rint(qa_uniform() * scale);
+    return gr_complex(re, im);
+}
+template <class FIR, class INFO, class I, class O, class TAP>
+static int qa_one_signature(const char *sig, void (*get_info)(std::vector<INFO> *), int MAX_TAPS, double tol, float scale)
+{
+    std::vector<INFO> info;
+    get_info(&info);
+    int fails = 0, cases = 0;
+    for (auto &p : info) {
+        srandom(0);          // we want reproducibility (qa_gr_fir_ccf.cc:118)
+        const int OUTPUT_LEN = 17, INPUT_LEN = MAX_TAPS + OUTPUT_LEN;
+        for (int n = 0; n <= MAX_TAPS; n++)
+            for (int ol = 0; ol <= OUTPUT_LEN; ol++) {
+                std::vector<I> input(INPUT_LEN);
+                std::vector<TAP> taps(MAX_TAPS);
+                for (auto &v : input) v = rnd_item<I>(scale);
+                for (auto &v : taps) v = rnd_item<TAP>(scale);
+                std::vector<TAP> f1_taps(taps.begin(), taps.begin() + n);
+                FIR *f1 = p.create(f1_taps);
+                std::vector<O> actual(OUTPUT_LEN, O());
+                f1->filterN(actual.data(), input.data(), ol);
+                for (int o = 0; o < ol; o++) {
+                    std::complex<double> sum = 0;
+                    for (int i = 0; i < n; i++) sum += std::complex<double>(input[o + i]) * std::complex<double>(taps[n - i - 1]);
+                    const std::complex<double> got(actual[o]);
+                    if (std::abs(got - sum) > std::abs(sum) * tol) fails++;
+                    cases++;
+                }
+                if (n > 0 && ol > 0) {       // filter() = one output (it may take another engine: same tolerance); get_taps()
+                    const std::complex<double> one(f1->filter(input.data()));
+                    std::complex<double> sum0 = 0;
+                    for (int i = 0; i < n; i++) sum0 += std::complex<double>(input[i]) * std::complex<double>(taps[n - i - 1]);
+                    if (std::abs(one - sum0) > std::abs(sum0) * tol) fails++;
+                    if (f1->get_taps() != f1_taps || f1->ntaps() != (unsigned)n) fails++;
+                }
+                delete f1;
+            }
+        // decimating form and set_taps (filterNdec: output[i] = filter(&input[i * decimate]), gr_fir_XXX.h.t:97-100)
+        {
+            const int T = 37, D = 3, N = 200;
+            std::vector<I> input((N - 1) * D + T);
+            std::vector<TAP> t1(5), t2(T);
+            for (auto &v : input) v = rnd_item<I>(scale);
+            for (auto &v : t1) v = rnd_item<TAP>(scale);
+            for (auto &v : t2) v = rnd_item<TAP>(scale);
+            FIR *f = p.create(t1);
+            f->set_taps(t2);
+            std::vector<O> out(N);
+            f->filterNdec(out.data(), input.data(), N, D);
+            for (int o = 0; o < N; o++) {
+                std::complex<double> sum = 0;
+                for (int i = 0; i < T; i++) sum += std::complex<double>(input[o * D + i]) * std::complex<double>(t2[T - i - 1]);
+                if (std::abs(std::complex<double>(out[o]) - sum) > std::abs(sum) * tol) fails++;
+                cases++;
+            }
+            delete f;
+        }
+        std::cout << " gr_fir_" << sig << " [" << p.name << "] " << cases << " outputs, " << fails << " wrong\n";
+    }
+    return fails + (info.empty() ? 1 : 0);
+}
+
+static int test_fir_qa()
+{
+    int fails = 0;
+    // taps range and tolerance per signature as in the reference: ccf / ccc 0..9 taps, |expected| * 1e-5
+    // (qa_gr_fir_ccf.cc:54,109, qa_gr_fir_ccc.cc:54); fff 0..32 taps, |expected| * 9e-3 (qa_gr_fir_fff.cc:147,189-190)
+    fails += qa_one_signature<gr_fir_ccf, gr_fir_ccf_info, gr_complex, gr_complex, float>("ccf", grhip_fir_sysconfig::get_gr_fir_ccf_info, 9, 1e-5, 32767.f);
+    fails += qa_one_signature<gr_fir_fff, gr_fir_fff_info, float, float, float>("fff", grhip_fir_sysconfig::get_gr_fir_fff_info, 32, 9e-3, 32768.f);
+    fails += qa_one_signature<gr_fir_ccc, gr_fir_ccc_info, gr_complex, gr_complex, gr_complex>("ccc", grhip_fir_sysconfig::get_gr_fir_ccc_info, 9, 1e-5, 32767.f);
+    std::cout << "fir qa: " << (fails ? "FAIL" : "ok") << "\n";
+    return fails;
+}
+
+// N-port adapters and the FFT block on its abstract base, through work() as the scheduler calls it
+static int test_adapters()
+{
+    int fails = 0;
+    const int NS = 5, N = 1000;
+    std::vector<gr_complex> x(NS * N);
+    for (int i = 0; i < NS * N; ++i) x[i] = gr_complex((float)i, (float)-i);
+    auto s2s = grhip_make_adapter<grhip_stream_to_streams_blk>(sizeof(gr_complex), (size_t)NS);
+    if (s2s->decimation() != (unsigned)NS || s2s->output_signature()->max_streams() != NS) fails++;
+    std::vector<std::vector<gr_complex>> streams(NS, std::vector<gr_complex>(N));
+    {
+        gr_vector_const_void_star in(1, x.data());
+        gr_vector_void_star out(NS);
+        for (int j = 0; j < NS; ++j) out[j] = streams[j].data();
+        if (s2s->work(N, in, out) != N) fails++;
+        for (int j = 0; j < NS; ++j)
+            for (int i = 0; i < N; ++i)
+                if (streams[j][i] != x[i * NS + j]) { fails++; break; }
+    }
+    auto back = grhip_make_adapter<grhip_streams_to_stream_blk>(sizeof(gr_complex), (size_t)NS);
+    {
+        std::vector<gr_complex> y(NS * N);
+        gr_vector_const_void_star in(NS);
+        for (int j = 0; j < NS; ++j) in[j] = streams[j].data();
+        gr_vector_void_star out(1, y.data());
+        if (back->interpolation() != (unsigned)NS || back->work(NS * N, in, out) != NS * N || y != x) fails++;
+    }
+    auto v2s = grhip_make_adapter<grhip_vector_to_streams_blk>(sizeof(gr_complex), (size_t)NS);
+    {
+        std::vector<std::vector<gr_complex>> o(NS, std::vector<gr_complex>(N));
+        gr_vector_const_void_star in(1, x.data());
+        gr_vector_void_star out(NS);
+        for (int j = 0; j < NS; ++j) out[j] = o[j].data();
+        if (v2s->work(N, in, out) != N || o != streams) fails++;
+    }
+    auto s2v = grhip_make_adapter<grhip_stream_to_vector_blk>(sizeof(gr_complex), (size_t)100);
+    {
+        std::vector<gr_complex> y(NS * N);
+        gr_vector_const_void_star in(1, x.data());
+        gr_vector_void_star out(1, y.data());
+        if (s2v->decimation() != 100 || s2v->work(NS * N / 100, in, out) != NS * N / 100 || y != x) fails++;
+    }
+    auto hd = grhip_make_adapter<grhip_head_blk>(sizeof(gr_complex), 1500ull);
+    {
+        std::vector<gr_complex> y(NS * N);
+        gr_vector_const_void_star in(1, x.data());
+        gr_vector_void_star out(1, y.data());
+        if (hd->work(1000, in, out) != 1000) fails++;
+        gr_vector_const_void_star in2(1, x.data() + 1000);
+        gr_vector_void_star out2(1, y.data() + 1000);
+        if (hd->work(1000, in2, out2) != 500) fails++;
+        if (hd->work(1000, in2, out2) != -1) fails++;                      // WORK_DONE, as gr_head.cc:49-50
+        for (int i = 0; i < 1500; ++i) if (y[i] != x[i]) { fails++; break; }
+        hd->reset();
+        if (hd->work(10, in, out) != 10) fails++;
+    }
+    // gr_fft_vcc_hip on the abstract base: the base class's (non-virtual) set_window reaches the device
+    {
+        const int F = 64;
+        gr_fft_vcc_hip_sptr f = gr_make_fft_vcc_hip(F, true, std::vector<float>());
+        gr_fft_vcc *base = f.get();
+        std::vector<gr_complex> in1(F, gr_complex(1.f, 0.f)), o1(F), o2(F);
+        gr_vector_const_void_star in(1, in1.data());
+        gr_vector_void_star out(1, o1.data());
+        if (f->work(1, in, out) != 1 || std::abs(o1[0] - gr_complex((float)F, 0.f)) > 1e-3f) fails++;
+        if (base->set_window(std::vector<float>(3, 1.f))) fails++;          // wrong size: refused (gr_fft_vcc.cc:57-63)
+        if (!base->set_window(std::vector<float>(F, 0.5f))) fails++;
+        gr_vector_void_star out2(1, o2.data());
+        if (f->work(1, in, out2) != 1 || std::abs(o2[0] - gr_complex(0.5f * F, 0.f)) > 1e-3f) fails++;
+        try { gr_make_fft_vcc_hip(0, true, std::vector<float>()); fails++; } catch (const std::out_of_range &) {}
+    }
+    std::cout << "adapters: " << (fails ? "FAIL" : "ok") << "\n";
+    return fails;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::cerr << "usage: host_chain_test <dir> <chain|errors|widened|tail>\n"; return 2; }
+    if (argc < 3) { std::cerr << "usage: host_chain_test <dir> <chain|errors|widened|tail|firqa|adapters>\n"; return 2; }
     std::string dir = argv[1], mode = argv[2];
     if (mode == "errors") return test_errors();
+    if (mode == "firqa") return test_fir_qa();
+    if (mode == "adapters") return test_adapters();
     if (mode == "widened") {
         // SURVEY 8f blocks through the block interface: fft_filter_ccc (output multiple nsamples) and
         // pager_slicer_fb -> unpack_k_bits_bb (gr_sync_interpolator), reference scheduler semantics for the tail
