@@ -7,7 +7,7 @@ import numpy as np
 __all__ = [
     "GrhipError", "lib", "lib_path", "strerror", "device_count", "set_default_mode",
     "MODE_FAST", "MODE_GENERIC", "MODE_FAST_VALU", "WORK_DONE",
-    "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc",
+    "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc", "fir_filter_with_buffer",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
     "clock_recovery_mm_ff", "clock_recovery_mm_cc", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "framer_sink_1_batch", "stream_to_streams", "streams_to_stream", "vector_to_streams", "stream_to_vector", "head",
     "fft_vcc", "fft_filter_ccc", "pfb_channelizer_ccf", "pfb_decimator_ccf", "dmr_chain", "run_sync_block",
@@ -190,6 +190,53 @@ class _fir_filter(_Block):
         L.grhip_fir_filterNdec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulong, C.c_uint]
         _check(L.grhip_fir_filterNdec(self._h, _ptr(out), _ptr(x), n, decimate))
         return out
+
+
+class fir_filter_with_buffer(_Block):
+    """gri_fir_filter_with_buffer_{ccf,ccc,fff}: the FIR kernel object that keeps its own delay line"""
+    _destroy = "grhip_fir_filter_with_buffer_destroy"
+
+    def __init__(self, kind, taps, device=0):
+        _Block.__init__(self)
+        self.kind = kind
+        self._tap = np.complex64 if kind == "ccc" else np.float32
+        self._io = np.float32 if kind == "fff" else np.complex64
+        t = np.ascontiguousarray(taps, dtype=self._tap)
+        L = lib()
+        L.grhip_fir_filter_with_buffer_create.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_void_p, C.c_size_t, C.c_int]
+        _check(L.grhip_fir_filter_with_buffer_create(C.byref(self._h), kind.encode(), _ptr(t), len(t), int(device)))
+
+    def set_taps(self, taps):
+        t = np.ascontiguousarray(taps, dtype=self._tap)
+        L = lib()
+        L.grhip_fir_filter_with_buffer_set_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        _check(L.grhip_fir_filter_with_buffer_set_taps(self._h, _ptr(t), len(t)))
+
+    def set_mode(self, mode):
+        _check(lib().grhip_fir_filter_with_buffer_set_mode(self._h, int(mode)))
+
+    def ntaps(self):
+        return _check(lib().grhip_fir_filter_with_buffer_ntaps(self._h))
+
+    def filterNdec(self, x, n, decimate=1):
+        x = np.ascontiguousarray(x, dtype=self._io)
+        if len(x) < n * decimate:
+            raise ValueError("filterNdec needs %d items" % (n * decimate))
+        out = np.zeros(n, dtype=self._io)
+        L = lib()
+        L.grhip_fir_filter_with_buffer_filterNdec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulong, C.c_ulong]
+        _check(L.grhip_fir_filter_with_buffer_filterNdec(self._h, _ptr(out), _ptr(x), n, decimate))
+        return out
+
+    def filterN(self, x, n):
+        return self.filterNdec(x, n, 1)
+
+    def filterNdec_device(self, d_out, d_in, n, decimate=1, stream=None):
+        L = lib()
+        L.grhip_fir_filter_with_buffer_filterNdec_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulong,
+                                                                     C.c_ulong, C.c_void_p]
+        _check(L.grhip_fir_filter_with_buffer_filterNdec_device(self._h, _devptr(d_out), _devptr(d_in), n, decimate,
+                                                                _stream(stream)))
 
 
 class fir_filter_ccf(_fir_filter):

@@ -692,6 +692,167 @@ int grhip_fir_filterNdec(grhip_fir_filter *h, void *output, const void *input, u
 }  // extern "C"
 
 // ============================================================================
+// gri_fir_filter_with_buffer_{ccf,ccc,fff}  (second half)
+//   filter/gri_fir_filter_with_buffer_XXX.h.t:44-126, .cc.t:30-121
+// The reference object owns its delay line (2 * ntaps items, zeroed by set_taps) and is called with NEW
+// samples only: filterNdec(out, in, n, dec) consumes n * dec items.  Here the delay line is the last
+// ntaps - 1 items, kept in HBM; a call lays [delay line | new items] out once and runs an engine of the FIR
+// family over it: out[o] = sum_k rev[k] * both[(dec - 1) + dec * o + k].  GENERIC mode uses the
+// reference's own accumulation order (one accumulator, term after term): bit-exact.
+// ============================================================================
+struct grhip_fir_filter_with_buffer : HandleBase {
+    FirKind kind = FIR_CCF;
+    int mode = GRHIP_MODE_FAST;
+    std::vector<float> taps;            // forward taps (x2 floats for ccc)
+    int ntaps = 0;
+    grhip_fir_filter *inner = nullptr;  // engines of the FIR family at the decimation last used
+    unsigned inner_dec = 0;
+    DevBuf d_hist, d_both;
+    size_t item() const { return kind == FIR_FFF ? 4 : 8; }
+    int tw() const { return kind == FIR_CCC ? 2 : 1; }
+    const char *kind_name() const { return kind == FIR_FFF ? "fff" : kind == FIR_CCF ? "ccf" : "ccc"; }
+    int ensure_inner(unsigned dec)
+    {
+        if (inner && inner_dec == dec) return GRHIP_OK;
+        if (inner) grhip_fir_filter_destroy(inner);
+        inner = nullptr;
+        int rc = grhip_fir_filter_create(&inner, kind_name(), (int)dec, taps.data(), (size_t)ntaps, device);
+        if (rc) return rc;
+        inner_dec = dec;
+        return GRHIP_OK;
+    }
+    int reset_line()
+    {
+        const size_t bytes = (size_t)(ntaps > 1 ? ntaps - 1 : 1) * item();
+        int rc = d_hist.reserve(bytes);
+        if (rc) return rc;
+        GRHIP_HIP(hipMemset(d_hist.p, 0, bytes));                       // memset(d_buffer, 0), .cc.t:55-57
+        return GRHIP_OK;
+    }
+};
+
+extern "C" {
+
+int grhip_fir_filter_with_buffer_create(grhip_fir_filter_with_buffer **h, const char *kind, const float *taps,
+                                        size_t ntaps, int device)
+{
+    if (!h || !kind) return fail(GRHIP_EINVAL, "null argument");
+    *h = nullptr;
+    FirKind k;
+    if (!strcmp(kind, "ccf")) k = FIR_CCF;
+    else if (!strcmp(kind, "fff")) k = FIR_FFF;
+    else if (!strcmp(kind, "ccc")) k = FIR_CCC;
+    else return fail(GRHIP_EINVAL, "unknown FIR kind '%s'", kind);
+    if (ntaps && !taps) return fail(GRHIP_EINVAL, "taps is NULL");
+    auto *f = new (std::nothrow) grhip_fir_filter_with_buffer();
+    if (!f) return fail(GRHIP_ENOMEM, "alloc");
+    f->kind = k; f->mode = default_mode();
+    int rc = f->init_device(device);
+    if (!rc) {
+        f->taps.assign(taps, taps + ntaps * f->tw());
+        f->ntaps = (int)ntaps;
+        rc = f->reset_line();
+    }
+    if (!rc) rc = f->ensure_inner(1);
+    if (rc) { grhip_fir_filter_with_buffer_destroy(f); return rc; }
+    *h = f;
+    return GRHIP_OK;
+}
+
+void grhip_fir_filter_with_buffer_destroy(grhip_fir_filter_with_buffer *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->inner) grhip_fir_filter_destroy(h->inner);
+    h->d_hist.release(); h->d_both.release();
+    h->destroy_base();
+    delete h;
+}
+
+// set_taps (.cc.t:44-59): new taps, delay line zeroed, takes effect at once (this is a kernel-level object,
+// not a block: there is no "returns 0 once")
+int grhip_fir_filter_with_buffer_set_taps(grhip_fir_filter_with_buffer *h, const float *taps, size_t ntaps)
+{
+    if (!h || (ntaps && !taps)) return fail(GRHIP_EINVAL, "null argument");
+    int rc = h->bind();
+    if (rc) return rc;
+    GRHIP_HIP(hipStreamSynchronize(h->own_stream));
+    h->taps.assign(taps, taps + ntaps * h->tw());
+    h->ntaps = (int)ntaps;
+    if (h->inner) { grhip_fir_filter_destroy(h->inner); h->inner = nullptr; h->inner_dec = 0; }
+    rc = h->reset_line();
+    if (!rc) rc = h->ensure_inner(1);
+    return rc;
+}
+
+int grhip_fir_filter_with_buffer_set_mode(grhip_fir_filter_with_buffer *h, int mode)
+{
+    if (!h || !mode_valid(mode)) return fail(GRHIP_EINVAL, "bad mode");
+    h->mode = mode;
+    return GRHIP_OK;
+}
+
+int grhip_fir_filter_with_buffer_ntaps(const grhip_fir_filter_with_buffer *h) { return h ? h->ntaps : GRHIP_EINVAL; }
+
+int grhip_fir_filter_with_buffer_filterNdec_device(grhip_fir_filter_with_buffer *h, void *d_output, const void *d_input,
+                                                   unsigned long n, unsigned long decimate, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (decimate < 1) return fail(GRHIP_EINVAL, "decimate must be >= 1");
+    if (n == 0) return GRHIP_OK;
+    if (!d_output || !d_input) return fail(GRHIP_EINVAL, "null buffer");
+    int rc = h->bind();
+    if (rc) return rc;
+    hipStream_t st = h->pick(stream);
+    const size_t it = h->item(), T = (size_t)h->ntaps, nin = (size_t)n * decimate;
+    if (T == 0) {                                   // no taps: every output is the empty sum
+        GRHIP_HIP(hipMemsetAsync(d_output, 0, (size_t)n * it, st));
+        return GRHIP_OK;
+    }
+    const size_t H = T - 1;
+    if ((rc = h->d_both.reserve((H + nin) * it + 64))) return rc;
+    unsigned char *both = h->d_both.as<unsigned char>();
+    if (H) GRHIP_HIP(hipMemcpyAsync(both, h->d_hist.p, H * it, hipMemcpyDeviceToDevice, st));
+    GRHIP_HIP(hipMemcpyAsync(both + H * it, d_input, nin * it, hipMemcpyDeviceToDevice, st));
+    const void *first = both + (decimate - 1) * it;         // window of output 0 ends at new item decimate - 1
+    if (!mode_fast(h->mode)) {
+        if ((rc = h->ensure_inner(h->inner_dec ? h->inner_dec : 1))) return rc;      // (its reversed taps on the device)
+        rc = launch_fir_generic(h->kind, h->inner->d_taps_rev.as<float>(), (int)T, first, d_output, (long long)n, (int)decimate,
+                                nullptr, st, true);
+    } else {
+        if ((rc = h->ensure_inner((unsigned)decimate))) return rc;
+        h->inner->mode = h->mode;
+        rc = h->inner->run(first, d_output, (long long)n, (int)decimate, st);
+    }
+    if (rc) return rc;
+    if (H) GRHIP_HIP(hipMemcpyAsync(h->d_hist.p, both + nin * it, H * it, hipMemcpyDeviceToDevice, st));   // the last ntaps - 1 items
+    return GRHIP_OK;
+}
+
+int grhip_fir_filter_with_buffer_filterNdec(grhip_fir_filter_with_buffer *h, void *output, const void *input, unsigned long n,
+                                            unsigned long decimate)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (decimate < 1) return fail(GRHIP_EINVAL, "decimate must be >= 1");
+    if (n == 0) return GRHIP_OK;
+    if (!output || !input) return fail(GRHIP_EINVAL, "null buffer");
+    int rc = h->bind();
+    if (rc) return rc;
+    const size_t it = h->item(), nin = (size_t)n * decimate;
+    if ((rc = h->stage_in.reserve(nin * it + 16))) return rc;
+    if ((rc = h->stage_out.reserve((size_t)n * it))) return rc;
+    hipStream_t st = h->own_stream;
+    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, input, nin * it, hipMemcpyHostToDevice, st));
+    rc = grhip_fir_filter_with_buffer_filterNdec_device(h, h->stage_out.p, h->stage_in.p, n, decimate, st);
+    if (rc) return rc;
+    GRHIP_HIP(hipMemcpyAsync(output, h->stage_out.p, (size_t)n * it, hipMemcpyDeviceToHost, st));
+    GRHIP_HIP(hipStreamSynchronize(st));
+    return GRHIP_OK;
+}
+
+}  // extern "C"
+
+// ============================================================================
 // gr_freq_xlating_fir_filter_ccc, gr_quadrature_demod_cf, fused hier block
 // ============================================================================
 struct grhip_freq_xlating_fir_filter_ccc : HandleBase {

@@ -13,8 +13,9 @@ enum FirKind { FIR_FFF = 0, FIR_CCF = 1, FIR_CCC = 2 };
 // for CCC.  in: device, item 0 = input[0] of output 0.  Any decimation.
 // epilogue: if gtab != nullptr (complex kinds) out[n] = rotate(out[n], gtab[n])
 // with the reference's unfused complex product (gr_rotator.h:43).
+// seq: one accumulator, terms in order (gri_fir_filter_with_buffer_XXX.cc.t:75-79) instead of the unrolled order
 int launch_fir_generic(FirKind kind, const float *taps_rev, int ntaps, const void *in, void *out,
-                       long long n_out, int decim, const float2 *gtab, hipStream_t st);
+                       long long n_out, int decim, const float2 *gtab, hipStream_t st, bool seq = false);
 
 // ---- (B) tiled fast kernel (complex data) ------------------------------------
 struct FirTiledArgs {

@@ -30,7 +30,9 @@ namespace grhip {
 // ===========================================================================
 // (A) generic-order kernel
 // ===========================================================================
-template <int KIND>
+// SEQ: ONE accumulator, terms added one after the other -- the order of
+// gri_fir_filter_with_buffer_XXX::filter (filter/gri_fir_filter_with_buffer_XXX.cc.t:75-79)
+template <int KIND, bool SEQ = false>
 __global__ void __launch_bounds__(256)
 fir_generic_kernel(const float *__restrict__ taps_rev, int ntaps, const float *__restrict__ in,
                    float *__restrict__ out, long long n_out, int decim,
@@ -43,6 +45,33 @@ fir_generic_kernel(const float *__restrict__ taps_rev, int ntaps, const float *_
     long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_out) return;
 
+    if (SEQ) {
+        if (KIND == FIR_FFF) {
+            const float *x = in + n * decim;
+            float acc = 0;
+            for (int i = 0; i < ntaps; i++) acc += x[i] * s_taps[i];
+            out[n] = acc;
+        } else {
+            const float2 *x = (const float2 *)in + n * decim;
+            float ar = 0, ai = 0;
+            if (KIND == FIR_CCF) {
+                for (int i = 0; i < ntaps; i++) {
+                    const float2 v = x[i];
+                    const float t = s_taps[i];
+                    const float pr = v.x * t, pi = v.y * t;
+                    ar += pr; ai += pi;
+                }
+            } else {
+                const float2 *tc = (const float2 *)s_taps;
+                for (int i = 0; i < ntaps; i++) {
+                    const float2 p = cmul_ref(x[i], tc[i]);
+                    ar += p.x; ai += p.y;
+                }
+            }
+            ((float2 *)out)[n] = make_float2(ar, ai);
+        }
+        return;
+    }
     if (KIND == FIR_FFF) {
         // N_UNROLL 4, float accumulators (.cc.t:30-55)
         const float *x = in + n * decim;
@@ -95,12 +124,33 @@ fir_generic_kernel(const float *__restrict__ taps_rev, int ntaps, const float *_
     }
 }
 
+template <int KIND, bool SEQ>
+static int launch_generic_inst(const float *taps_rev, int ntaps, const void *in, void *out, long long n_out, int decim,
+                               size_t sh, hipStream_t st)
+{
+    dim3 grid((unsigned)((n_out + 255) / 256)), block(256);
+    if (sh > 64 * 1024)
+        GRHIP_HIP(hipFuncSetAttribute((const void *)fir_generic_kernel<KIND, SEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL((fir_generic_kernel<KIND, SEQ>), grid, block, sh, st, taps_rev, ntaps, (const float *)in, (float *)out, n_out,
+                       decim, (const float2 *)nullptr);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
 int launch_fir_generic(FirKind kind, const float *taps_rev, int ntaps, const void *in, void *out,
-                       long long n_out, int decim, const float2 *gtab, hipStream_t st)
+                       long long n_out, int decim, const float2 *gtab, hipStream_t st, bool seq)
 {
     if (n_out <= 0) return GRHIP_OK;
     size_t sh = (size_t)(ntaps > 0 ? ntaps : 1) * (kind == FIR_CCC ? 8 : 4);
     if (sh > 160 * 1024 - 256) return fail(GRHIP_EINVAL, "generic FIR: %d taps exceed LDS", ntaps);
+    if (seq) {
+        if (gtab) return fail(GRHIP_EINVAL, "sequential-order FIR has no rotator epilogue");
+        switch (kind) {
+        case FIR_FFF: return launch_generic_inst<FIR_FFF, true>(taps_rev, ntaps, in, out, n_out, decim, sh, st);
+        case FIR_CCF: return launch_generic_inst<FIR_CCF, true>(taps_rev, ntaps, in, out, n_out, decim, sh, st);
+        default: return launch_generic_inst<FIR_CCC, true>(taps_rev, ntaps, in, out, n_out, decim, sh, st);
+        }
+    }
     dim3 grid((unsigned)((n_out + 255) / 256)), block(256);
     switch (kind) {
     case FIR_FFF:

@@ -235,12 +235,13 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int LANE_BYTES = FP ? 8 : 16;         // bytes between the loads of neighbouring lanes
+    int lead = 0;       // set by tile_geom
     auto tile_geom = [&](int s, int b, __amdgpu_buffer_rsrc_t &rsrc, int &voff, int &off) {
         const long long g0 = ((long long)b * NTE - OVL - 1) * D - a.n_lo;   // tile start relative to the first real item
         if (FP) {
             // items are floats; strides and counts of the launch are in floats
             const float *xf = reinterpret_cast<const float *>(a.x) + (long long)s * a.x_stride + a.n_lo;
-            off = 0;
+            off = 0; lead = 0;
             const long long bytes = (a.ablate & 1) ? 0 : (a.n_in - a.n_lo) * 4;
             rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xf), 0, (int)bytes, 0x00020000);
             voff = (int)(g0 * 4) + LANE_BYTES * t;
@@ -249,9 +250,15 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
         const float2 *x = a.x + (long long)s * a.x_stride + a.n_lo;       // first real item
         const long long unit0 = (long long)(((unsigned long long)(uintptr_t)x) >> 3) + g0;
         off = (int)(unit0 & 1);                     // pair starts on a 16-byte boundary
-        const long long bytes = (a.ablate & 1) ? 0 : (a.n_in - a.n_lo) * 8;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x), 0, (int)bytes, 0x00020000);
-        voff = (int)((g0 - off) * 8) + LANE_BYTES * t;      // may be negative: out of range => zeros
+        // The descriptor must start on a 16-byte boundary too: a 16-byte load at offset -8 is out of range as a
+        // WHOLE (no per-dword wrap-around), which would lose the stream's first item.  When that item sits on an
+        // odd 8-byte unit (lead = 1) the descriptor starts one item earlier -- the same 16-byte granule, hence the
+        // same allocation -- and stage() zeroes that item where a window can see it (round 2 fix: a stream that
+        // started 8 bytes off a 16-byte boundary lost its first item; no caller of round 1 produced one).
+        lead = (int)((((unsigned long long)(uintptr_t)x) >> 3) & 1);
+        const long long bytes = (a.ablate & 1) ? 0 : (a.n_in - a.n_lo + lead) * 8;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x - lead), 0, (int)bytes, 0x00020000);
+        voff = (int)((g0 - off + lead) * 8) + LANE_BYTES * t;      // may be negative: out of range => zeros
     };
 
     // ---- rotator phases of a tile's outputs (issued at the end of the previous tile:
@@ -295,6 +302,12 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
     auto stage = [&](int s, int b) {
         __amdgpu_buffer_rsrc_t rsrc; int voff, off;
         tile_geom(s, b, rsrc, voff, off);
+        if (!FP && lead && b == 0 && a.n_lo > 0) {
+            // the item in front of a stream that starts off a 16-byte boundary is a history zero
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (voff + i * (LANE_BYTES * TILED_THREADS) == 0) { pf[i].x = 0.f; pf[i].y = 0.f; }
+        }
         if (PREMIX && off != w_off) {       // wave-uniform, first tile only in practice
             const f32x2 w0l = off ? wA : wB;
             const f32x2 *st = reinterpret_cast<const f32x2 *>(a.stab);

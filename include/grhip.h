@@ -116,6 +116,29 @@ GRHIP_API int grhip_fir_filterNdec(grhip_fir_filter *h, void *output, const void
                                    unsigned long n, unsigned decimate);
 
 /* ======================================================================
+ * gri_fir_filter_with_buffer_{ccf,ccc,fff}  (the FIR kernel object that owns its delay line)
+ *   replaces gri_fir_filter_with_buffer_XXX(const std::vector<TAP> &taps)
+ *   filter/gri_fir_filter_with_buffer_XXX.h.t:44-126, .cc.t:30-121
+ * kind "ccf" | "ccc" | "fff"; taps in forward order.  filterNdec(output, input, n, decimate) takes NEW items
+ * only (n * decimate of them) -- output[i] = filter(&input[i * decimate], decimate), .cc.t:110-121; filterN is
+ * decimate = 1 and filter(x) is n = 1 -- and continues from the delay line the previous calls left
+ * (zeros after create / set_taps, .cc.t:44-59).  GRHIP_MODE_GENERIC accumulates in the reference's order
+ * (one accumulator, term after term, .cc.t:75-79): bit-exact.  A kernel-level object: set_taps acts at once.
+ * ====================================================================== */
+typedef struct grhip_fir_filter_with_buffer grhip_fir_filter_with_buffer;
+GRHIP_API int grhip_fir_filter_with_buffer_create(grhip_fir_filter_with_buffer **h, const char *kind, const float *taps,
+                                                  size_t ntaps, int device);
+GRHIP_API void grhip_fir_filter_with_buffer_destroy(grhip_fir_filter_with_buffer *h);
+GRHIP_API int grhip_fir_filter_with_buffer_set_taps(grhip_fir_filter_with_buffer *h, const float *taps, size_t ntaps);
+GRHIP_API int grhip_fir_filter_with_buffer_set_mode(grhip_fir_filter_with_buffer *h, int mode);
+GRHIP_API int grhip_fir_filter_with_buffer_ntaps(const grhip_fir_filter_with_buffer *h);
+GRHIP_API int grhip_fir_filter_with_buffer_filterNdec(grhip_fir_filter_with_buffer *h, void *output, const void *input,
+                                                      unsigned long n, unsigned long decimate);
+GRHIP_API int grhip_fir_filter_with_buffer_filterNdec_device(grhip_fir_filter_with_buffer *h, void *d_output,
+                                                             const void *d_input, unsigned long n,
+                                                             unsigned long decimate, void *stream);
+
+/* ======================================================================
  * gr_freq_xlating_fir_filter_ccc
  *   replaces gr_make_freq_xlating_fir_filter_ccc(int decimation,
  *       const std::vector<gr_complex>& taps, double center_freq, double sampling_freq)

@@ -1058,4 +1058,77 @@ ORC_API int orc_chain_mm(float omega, float gain_omega, float mu, float gain_mu,
         final_state[3] = (float)consumed;
     }
     return n;
+}/* ==========================================================================
+ * gri_fir_filter_with_buffer_{ccf,ccc,fff}
+ *   gnuradio-core/src/lib/filter/gri_fir_filter_with_buffer_XXX.cc.t:30-121
+ * The filter owns its delay line: a buffer of 2*ntaps items written twice (d_idx and d_idx + ntaps,
+ * .cc.t:65-66), zeroed by set_taps (.cc.t:55-57); one output per `dec` inputs is the dot product of the
+ * reversed taps with the last ntaps inputs, accumulated one term after the other in the
+ * accumulator type (.cc.t:75-79): ONE accumulator, sequential -- not gr_fir_XXX_generic's unrolled order.
+ * kind: 0 fff, 1 ccf, 2 ccc.  The state lives in an opaque object so that calls continue each other.
+ * ========================================================================== */
+typedef struct {
+    int kind;
+    unsigned ntaps, idx;
+    float *dt;      /* reversed taps (.cc.t:46), complex interleaved for ccc */
+    float *buf;     /* 2 * ntaps items */
+} orc_fwb;
+
+ORC_API orc_fwb *orc_fwb_create(int kind, const float *taps_fwd, unsigned ntaps)
+{
+    orc_fwb *f = (orc_fwb *)calloc(1, sizeof(orc_fwb));
+    const unsigned tw = kind == 2 ? 2 : 1, iw = kind == 0 ? 1 : 2;
+    f->kind = kind; f->ntaps = ntaps; f->idx = 0;
+    f->dt = reversed(taps_fwd, ntaps, tw);
+    f->buf = (float *)calloc((size_t)2 * (ntaps ? ntaps : 1) * iw, sizeof(float));      /* memset 0, .cc.t:55-57 */
+    return f;
 }
+
+ORC_API void orc_fwb_destroy(orc_fwb *f)
+{
+    if (!f) return;
+    free(f->dt); free(f->buf); free(f);
+}
+
+/* filterNdec (.cc.t:110-121): output[i] = filter(&input[i * decimate], decimate) */
+ORC_API void orc_fwb_filterNdec(orc_fwb *f, const float *in, float *out, size_t n, unsigned dec)
+{
+    const unsigned T = f->ntaps, iw = f->kind == 0 ? 1 : 2;
+    for (size_t o = 0; o < n; ++o) {
+        for (unsigned i = 0; i < dec; ++i) {                     /* .cc.t:88-94 */
+            const float *x = in + (o * dec + i) * iw;
+            if (T) {     /* (with no taps the reference writes into a zero-sized buffer; nothing is read back) */
+                for (unsigned w = 0; w < iw; ++w) {
+                    f->buf[(size_t)f->idx * iw + w] = x[w];
+                    f->buf[(size_t)(f->idx + T) * iw + w] = x[w];
+                }
+            }
+            f->idx++;
+            if (f->idx >= T) f->idx = 0;
+        }
+        if (f->kind == 0) {
+            float acc = 0;                                        /* .cc.t:96-99 */
+            for (unsigned i = 0; i < T; ++i) acc += f->buf[f->idx + i] * f->dt[i];
+            out[o] = acc;
+        } else if (f->kind == 1) {
+            float ar = 0, ai = 0;                                 /* complex<float> * float, then += */
+            for (unsigned i = 0; i < T; ++i) {
+                const float pr = f->buf[2 * (size_t)(f->idx + i)] * f->dt[i];
+                const float pi = f->buf[2 * (size_t)(f->idx + i) + 1] * f->dt[i];
+                ar += pr; ai += pi;
+            }
+            out[2 * o] = ar; out[2 * o + 1] = ai;
+        } else {
+            float ar = 0, ai = 0;
+            for (unsigned i = 0; i < T; ++i) {
+                float pr, pi;
+                cmul(f->buf[2 * (size_t)(f->idx + i)], f->buf[2 * (size_t)(f->idx + i) + 1], f->dt[2 * i], f->dt[2 * i + 1],
+                     &pr, &pi);
+                ar += pr; ai += pi;
+            }
+            out[2 * o] = ar; out[2 * o + 1] = ai;
+        }
+    }
+}
+
+

@@ -72,6 +72,47 @@ def fir_ccc(taps, x, n, decim=1):
     return _fir("orc_fir_ccc", taps, True, x, True, n, decim)
 
 
+class FirFilterWithBuffer(object):
+    """gri_fir_filter_with_buffer_{fff,ccf,ccc} (filter/gri_fir_filter_with_buffer_XXX.cc.t:30-121): the filter keeps
+    its own delay line across calls; filterNdec(x, n, dec) consumes n * dec items"""
+    KINDS = {"fff": 0, "ccf": 1, "ccc": 2}
+
+    def __init__(self, kind, taps):
+        o = _need()
+        self.kind = kind
+        self._k = self.KINDS[kind]
+        self._tap_dt = np.complex64 if kind == "ccc" else np.float32
+        self._io_dt = np.float32 if kind == "fff" else np.complex64
+        o.orc_fwb_create.restype = C.c_void_p
+        o.orc_fwb_create.argtypes = [C.c_int, C.c_void_p, C.c_uint]
+        o.orc_fwb_destroy.argtypes = [C.c_void_p]
+        o.orc_fwb_filterNdec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint]
+        o.orc_fwb_filterNdec.restype = None
+        self._o = o
+        self._h = None
+        self.set_taps(taps)
+
+    def set_taps(self, taps):
+        t = np.ascontiguousarray(taps, dtype=self._tap_dt)
+        if self._h:
+            self._o.orc_fwb_destroy(self._h)
+        self._h = self._o.orc_fwb_create(self._k, t.ctypes.data, len(t))
+
+    def filterNdec(self, x, n, dec=1):
+        x = np.ascontiguousarray(x, dtype=self._io_dt)
+        assert len(x) >= n * dec
+        out = np.zeros(n, dtype=self._io_dt)
+        self._o.orc_fwb_filterNdec(self._h, x.ctypes.data, out.ctypes.data, n, dec)
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._o.orc_fwb_destroy(self._h)
+        except Exception:
+            pass
+
+
 def fast_atan2f(y, x):
     o = _need()
     y = np.ascontiguousarray(y, dtype=np.float32).ravel()
