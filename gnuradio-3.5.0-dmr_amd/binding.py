@@ -719,6 +719,12 @@ class framer_sink_1(_Block):
         L.grhip_framer_sink_1_work.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         return _check(L.grhip_framer_sink_1_work(self._h, int(noutput_items), _ptr(x)))
 
+    def set_segment_items(self, items):
+        """tuning: items per segment of the parallel walk of long calls (0 = automatic); results do not depend on it"""
+        L = lib()
+        L.grhip_framer_sink_1_set_segment_items.argtypes = [C.c_void_p, C.c_longlong]
+        _check(L.grhip_framer_sink_1_set_segment_items(self._h, int(items)))
+
     def work_device(self, noutput_items, d_in, stream=None):
         L = lib()
         L.grhip_framer_sink_1_work_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

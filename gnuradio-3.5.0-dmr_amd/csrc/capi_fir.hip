@@ -59,11 +59,13 @@ static int build_mfma_taps(const float *c, int T, int D, DevBuf (&dA)[2], int *k
 // the high-decimation direct kernel where it beats (or replaces) the overlap-save engine
 static bool hidec_wanted(int decim, int ntaps, bool ctaps, bool have_ols)
 {
-    static int knob = -1;                                  // GRHIP_HIDEC=0 / 1: tuning knob (never / whenever supported)
-    if (knob < 0) { const char *e = getenv("GRHIP_HIDEC"); knob = e ? 2 + atoi(e) : 0; }
     if (!hidec_supported(decim, ntaps)) return false;
+#ifdef GRHIP_DIAG       // diagnostic builds only: GRHIP_HIDEC=0 / 1 = never / whenever supported (tools/bench_decim.py)
+    static int knob = -1;
+    if (knob < 0) { const char *e = getenv("GRHIP_HIDEC"); knob = e ? 2 + atoi(e) : 0; }
     if (knob == 2) return false;
     if (knob == 3) return true;
+#endif
     if (!have_ols) return true;
     // work per input sample in units the measurements line up on (tools/bench_decim.py): taps per polyphase
     // component, twice for complex taps, over the share of lanes a tile keeps busy

@@ -556,6 +556,7 @@ framer_compact_kernel(FramerState *S, unsigned char *pool)
 struct grhip_framer_sink_1 : HandleBase {
     DevBuf d_state, d_F, d_D, d_jobs, d_msgs, d_pool, d_recs, d_segs;
     size_t msg_bound = 0, pool_bound = 4096;     // upper bounds of what un-fetched calls can have produced
+    long long seg_items = 0;                     // items per segment of the parallel walk; 0 = chosen per call
     // host copy of the last fetch
     std::vector<FramerMsg> h_msgs;
     std::vector<unsigned char> h_pool;
@@ -598,6 +599,13 @@ void grhip_framer_sink_1_destroy(grhip_framer_sink_1 *h)
     delete h;
 }
 
+int grhip_framer_sink_1_set_segment_items(grhip_framer_sink_1 *h, long long items)
+{
+    if (!h || items < 0) return fail(GRHIP_EINVAL, "bad argument");
+    h->seg_items = items;
+    return GRHIP_OK;
+}
+
 int grhip_framer_sink_1_work_device(grhip_framer_sink_1 *h, int noutput_items, const unsigned char *d_in, void *stream)
 {
     if (!h) return fail(GRHIP_EINVAL, "null handle");
@@ -625,7 +633,7 @@ int grhip_framer_sink_1_work_device(grhip_framer_sink_1 *h, int noutput_items, c
     // walk about 0.63 us per 1000 items, so the two balance near seg = sqrt(160 n) (tools/bench_framer.py)
     long long seg = 4096;
     while (4 * seg * seg <= 160 * n && seg < (1ll << 20)) seg <<= 1;
-    if (const char *e = getenv("GRHIP_FRAMER_SEG")) seg = std::max(64ll, atoll(e));       // tuning / test knob
+    if (h->seg_items > 0) seg = std::max<long long>(64, h->seg_items);      // grhip_framer_sink_1_set_segment_items
     const long long nseg = (n + seg - 1) / seg;
     if (nseg >= 4) {
         const size_t reccap = (size_t)seg / 32 + 2;

@@ -42,8 +42,6 @@ struct FirTiledArgs {
     int vec_store;          // 1 if output rows are 16-byte aligned
     int fpair;              // 0: complex items; 1/2: float-pair mode of gr_fir_fff with that decimation
     unsigned *sched;        // 2 zero-initialised counters owned by the caller (tile queue), or null: static split
-    int skew_mode, skew_sleeps;   // start-up skew between the workgroups sharing a CU (filled in by the launcher)
-    int ablate;             // profiling only (env GRHIP_ABLATE): 1 skip global loads
 };
 
 // EPI_DEMOD (pre-mix form only): the demodulator works on the pre-mixed accumulators

@@ -42,11 +42,6 @@ namespace grhip {
 
 // R = outputs per lane.  R = 8: one LDS read per 8 packed FMAs, 2 workgroups (8 waves)
 // per CU.  R = 4: twice the LDS reads per FMA but 3 workgroups (12 waves) per CU.
-#ifndef GRHIP_EXP
-#define GRHIP_EXP 0        // timing experiments only (wrong results): 1 no tap loads, 2 no window loads in the MAC loop,
-                           // 4 prefetch in one burst before the MAC loop, 8 no MAC loop, 16 no demodulator arithmetic,
-                           // 32 wave priority by phase (no effect), 64 first blocks of a pass requested a pass ahead
-#endif
 #ifndef GRHIP_TILED_R
 #define GRHIP_TILED_R 8
 #endif
@@ -242,7 +237,7 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
             // items are floats; strides and counts of the launch are in floats
             const float *xf = reinterpret_cast<const float *>(a.x) + (long long)s * a.x_stride + a.n_lo;
             off = 0; lead = 0;
-            const long long bytes = (a.ablate & 1) ? 0 : (a.n_in - a.n_lo) * 4;
+            const long long bytes = (a.n_in - a.n_lo) * 4;
             rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xf), 0, (int)bytes, 0x00020000);
             voff = (int)(g0 * 4) + LANE_BYTES * t;
             return;
@@ -256,7 +251,7 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
         // same allocation -- and stage() zeroes that item where a window can see it (round 2 fix: a stream that
         // started 8 bytes off a 16-byte boundary lost its first item; no caller of round 1 produced one).
         lead = (int)((((unsigned long long)(uintptr_t)x) >> 3) & 1);
-        const long long bytes = (a.ablate & 1) ? 0 : (a.n_in - a.n_lo + lead) * 8;
+        const long long bytes = (a.n_in - a.n_lo + lead) * 8;
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x - lead), 0, (int)bytes, 0x00020000);
         voff = (int)((g0 - off + lead) * 8) + LANE_BYTES * t;      // may be negative: out of range => zeros
     };
@@ -364,11 +359,6 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
     unsigned *sched_slot = reinterpret_cast<unsigned *>(smem + (size_t)D * PS * sizeof(float2));
     int s = 0, bidx = 0;
     decode(cur, s, bidx);
-    if (a.skew_sleeps > 0) {
-        const bool late = a.skew_mode == 1 ? blockIdx.x >= gridDim.x / 2 : (blockIdx.x & 1);
-        if (late)
-            for (int i = 0; i < a.skew_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     if (cur < total_tiles) {
         __amdgpu_buffer_rsrc_t rsrc; int voff, off;
         tile_geom(s, bidx, rsrc, voff, off);
@@ -383,9 +373,6 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
         decode(nxt, s_nxt, b_nxt);
 
         STAMP(7);
-#if GRHIP_EXP & 32
-        __builtin_amdgcn_s_setprio(3);      // the latency-bound phases take issue slots as soon as they can use them
-#endif
         stage(s, bidx);
         STAMP(0);
         __syncthreads();
@@ -398,9 +385,6 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
         if (nxt >= total_tiles) voff_n = 0x7ffff000 - NI * LANE_BYTES * TILED_THREADS;   // out of range: zeros, no traffic
         unsigned nn = nxt + G;
         if (a.sched && t == 0) nn = atomicAdd(a.sched, 1u) + 2u * G;       // arrives during the MAC loop
-#if GRHIP_EXP & 4
-        fetch(rsrc_n, voff_n, -1);
-#endif
         STAMP(2);
 
         STAMP(3);
@@ -419,9 +403,6 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
         const int lane_base = (tl + 1) * R + (tl + 1);     // slot of mm = (tl+1)R
         const int nb = Tq >> LOGR;                         // steps per pass
         tapvec hcur = *reinterpret_cast<const tapvec __attribute__((address_space(4))) *>(hp);
-#if GRHIP_EXP & 32
-        __builtin_amdgcn_s_setprio(0);      // the MAC loop fills what is left
-#endif
 
         // Real taps: one step is ONE asm statement -- the scalar load of the next step's
         // taps, the 64 packed FMAs (tap = one half of an SGPR pair, chosen with op_sel) and
@@ -464,51 +445,24 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
             }
         };
 
-#if GRHIP_EXP & 8
-        fetch(rsrc_n, voff_n, -1);
-#else
-#if GRHIP_EXP & 64
-        // first two sample blocks of a pass, requested one pass ahead (the first step of a pass would
-        // otherwise wait for them)
-        f32x2 nA[R], nB[R];
-        {
-            const f32x2 *x0 = reinterpret_cast<const f32x2 *>(xs) + lane_base;
-#pragma unroll
-            for (int j = 0; j < R; ++j) { nA[j] = x0[j]; nB[j] = x0[(R + 1) + j]; }
-        }
-#endif
 #pragma unroll
         for (int p = 0; p < D; ++p) {
             const f32x2 *xp = reinterpret_cast<const f32x2 *>(xs) + p * PS + lane_base;
             f32x2 wA[R], wB[R], wC[R];
             auto load_blk = [&](f32x2 (&dst)[R], int blk) {
-#if !(GRHIP_EXP & 2)
 #pragma unroll
                 for (int j = 0; j < R; ++j) dst[j] = xp[blk * (R + 1) + j];
-#endif
             };
             auto step = [&](const f32x2 (&cur)[R], const f32x2 (&nxt)[R], f32x2 (&ld)[R], int k) {
                 load_blk(ld, k + 2);
                 if (CTAPS) step_cplx(cur, nxt, p * nb + k);
                 else step_real(cur, nxt, p * nb + k);
             };
-#if GRHIP_EXP & 64
-#pragma unroll
-            for (int j = 0; j < R; ++j) { wA[j] = nA[j]; wB[j] = nB[j]; }
-            if (p + 1 < D) {
-                const f32x2 *x1 = xp + PS;
-#pragma unroll
-                for (int j = 0; j < R; ++j) { nA[j] = x1[j]; nB[j] = x1[(R + 1) + j]; }
-            }
-#else
             load_blk(wA, 0);
             load_blk(wB, 1);
-#endif
-#if !(GRHIP_EXP & 4)
             // this pass's share of the next tile's HBM loads, issued while the first two sample
             // blocks are on their way from LDS (p is a compile-time constant: the pass loop is unrolled)
             fetch(rsrc_n, voff_n, p);
-#endif
             int k = 0;
             for (; k + 3 <= nb; k += 3) {
                 step(wA, wB, wC, k);
@@ -518,16 +472,12 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
             if (k < nb) step(wA, wB, wC, k);
             if (k + 1 < nb) step(wB, wC, wA, k + 1);
         }
-#endif
 
         float2 acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = make_float2(av[r].x, av[r].y);
 
         STAMP(4);
-#if GRHIP_EXP & 32
-        __builtin_amdgcn_s_setprio(3);
-#endif
         // ---------------- epilogue ---------------------------------------------------
         const long long nl = n0 + (long long)tl * R;         // first output of this lane
         if (PREMIX && !DIRECT) {
@@ -567,11 +517,7 @@ __global__ void __launch_bounds__(TILED_THREADS, tiled_wg_per_cu(D, PREMIX, EPI)
             float d[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-#if GRHIP_EXP & 16
-                d[r] = acc[r].x + prev.y;
-#else
                 d[r] = quad_demod_fast(acc[r], prev, a.gain, s_atan);
-#endif
                 prev = acc[r];
             }
             float *__restrict__ o = a.d_out + s * a.d_stride;
@@ -646,9 +592,12 @@ static int launch_tiled_inst(const FirTiledArgs &a, hipStream_t st)
     }
     constexpr int NEW_PER_TILE = EPI == EPI_DEMOD ? TILED_NT - TILED_R * (TILED_THREADS / 64) : TILED_NT;
     const long long tiles = ((a.n_out + NEW_PER_TILE - 1) / NEW_PER_TILE) * a.n_streams;
+    int wgs = tiled_wg_per_cu(D, PREMIX, EPI);
+#ifdef GRHIP_DIAG       // diagnostic builds only (make variant EXTRA=-DGRHIP_DIAG): persistent workgroups per CU
     static int wg_per_cu = 0;
-    if (!wg_per_cu) { const char *e = getenv("GRHIP_WGPCU"); wg_per_cu = e ? atoi(e) : -1; }   // tuning knob
-    int wgs = wg_per_cu > 0 ? wg_per_cu : tiled_wg_per_cu(D, PREMIX, EPI);
+    if (!wg_per_cu) { const char *e = getenv("GRHIP_WGPCU"); wg_per_cu = e ? atoi(e) : -1; }
+    if (wg_per_cu > 0) wgs = wg_per_cu;
+#endif
     const int fit = (int)((160 * 1024) / (lds + 256));                 // what the LDS tile allows
     if (wgs > fit) wgs = fit < 1 ? 1 : fit;
     long long grid = (long long)wgs * g_num_cus;   // persistent workgroups
@@ -707,16 +656,6 @@ int launch_fir_tiled(int decim, bool ctaps, bool premix, int epi, const FirTiled
     }
     FirTiledArgs a = a_in;
     a.n_streams = n_streams;
-    static int ablate = -1;
-    if (ablate < 0) { const char *e = getenv("GRHIP_ABLATE"); ablate = e ? atoi(e) : 0; }
-    a.ablate = ablate;
-    static int skew_mode = -1, skew_sleeps = 0;
-    if (skew_mode < 0) {
-        const char *e = getenv("GRHIP_SKEW");        // "mode,sleeps" (tuning knob)
-        skew_mode = 0;
-        if (e) sscanf(e, "%d,%d", &skew_mode, &skew_sleeps);
-    }
-    a.skew_mode = skew_mode; a.skew_sleeps = skew_sleeps;
     // the tile queue's counter round trip hides under the MAC loop of a long filter only;
     // short filters keep the static split
     if (a.Tq * decim < 128) a.sched = nullptr;

@@ -396,6 +396,9 @@ GRHIP_API int grhip_pfb_decimator_ccf_work_device(grhip_pfb_decimator_ccf *h, in
 typedef struct grhip_framer_sink_1 grhip_framer_sink_1;
 GRHIP_API int grhip_framer_sink_1_create(grhip_framer_sink_1 **h, int device);
 GRHIP_API void grhip_framer_sink_1_destroy(grhip_framer_sink_1 *h);
+/* tuning: items per segment of the segment-parallel walk of long calls (0 = chosen per call, about sqrt(160 n);
+ * results do not depend on it -- the tests use 64 to force the walk's divergence branch) */
+GRHIP_API int grhip_framer_sink_1_set_segment_items(grhip_framer_sink_1 *h, long long items);
 GRHIP_API int grhip_framer_sink_1_work(grhip_framer_sink_1 *h, int noutput_items, const unsigned char *in);
 GRHIP_API int grhip_framer_sink_1_work_device(grhip_framer_sink_1 *h, int noutput_items, const unsigned char *d_in,
                                               void *stream);

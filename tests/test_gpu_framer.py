@@ -117,32 +117,36 @@ def test_framer_after_correlator(gpu, po, wl):
     assert len(got) >= 35 and all(m in sent for m in got)
 
 
+def _framer(gpu, seg):
+    f = gpu.framer_sink_1()
+    f.set_segment_items(seg)
+    return f
+
+
 @pytest.mark.parametrize("seg", [64, 320, 4096, 65536])
 @pytest.mark.parametrize("seed,gap,maxlen", [(20, 200, 64), (21, 30, 10), (22, 3000, 900), (23, 1, 4095), (24, 500, 0)])
-def test_framer_segment_parallel_walk(gpu, po, monkeypatch, seg, seed, gap, maxlen):
-    """long calls take the segment-parallel walk (speculative per-segment walks + serial fix-up); GRHIP_FRAMER_SEG
+def test_framer_segment_parallel_walk(gpu, po, seg, seed, gap, maxlen):
+    """long calls take the segment-parallel walk (speculative per-segment walks + serial fix-up); set_segment_items
     shrinks the segments so that packets straddle many of them and the fix-up's divergence branch is exercised"""
-    monkeypatch.setenv("GRHIP_FRAMER_SEG", str(seg))
     rng = np.random.default_rng(seed)
     n = 300_000
     x = make_stream(rng, n, gap, maxlen, stray_flags=0.004)
     ref = ref_chunks(po, x, [])
-    assert run_chunks(gpu.framer_sink_1(), x, []) == ref
+    assert run_chunks(_framer(gpu, seg), x, []) == ref
     cuts = sorted(int(c) for c in rng.integers(0, n, 4))
-    assert run_chunks(gpu.framer_sink_1(), x, cuts) == ref_chunks(po, x, [])
+    assert run_chunks(_framer(gpu, seg), x, cuts) == ref_chunks(po, x, [])
     dense = rng.integers(0, 4, 100_000, dtype=np.uint8)
-    assert run_chunks(gpu.framer_sink_1(), dense, [33_333]) == ref_chunks(po, dense, [])
+    assert run_chunks(_framer(gpu, seg), dense, [33_333]) == ref_chunks(po, dense, [])
 
 
-def test_framer_parallel_walk_inside_a_long_packet(gpu, po, monkeypatch):
+def test_framer_parallel_walk_inside_a_long_packet(gpu, po):
     """calls that begin and end inside one 4095-byte packet, on the segment-parallel path (the speculative
     segments of such a call must contribute nothing), then packets again"""
-    monkeypatch.setenv("GRHIP_FRAMER_SEG", "64")
     rng = np.random.default_rng(31)
     x = make_stream(rng, 120_000, 5, 4095, bad=0.0, stray_flags=0.01)
     ref = ref_chunks(po, x, [])
     assert any(len(m[1]) > 2000 for m in ref)
     cuts = list(range(700, len(x), 1000))                     # 1000-item calls: 16 segments each
-    assert run_chunks(gpu.framer_sink_1(), x, cuts) == ref
+    assert run_chunks(_framer(gpu, 64), x, cuts) == ref
     cuts = list(range(31, len(x), 257))                       # header bits split across calls as well
-    assert run_chunks(gpu.framer_sink_1(), x, cuts) == ref
+    assert run_chunks(_framer(gpu, 64), x, cuts) == ref

@@ -1,4 +1,5 @@
 # shader clock and VALU utilisation of the tiled kernel at 1 and 2 workgroups per CU
+# (GRHIP_WGPCU is honoured by diagnostic builds only: make variant NAME=diag EXTRA=-DGRHIP_DIAG, GRHIP_LIB=.../libgrhip_diag.so)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_clk
