@@ -68,11 +68,16 @@ template <int D, int KS> struct Geo {
     static constexpr int SP = mf::tile_samples(D, KS);
     static constexpr int NI = mf::rounds(D, KS);
     static constexpr int PL = mf::plane_bytes(D, KS);
-    static constexpr int OFF_SCR = 4 * PL;
-    static constexpr int OFF_ATAN = OFF_SCR + mf::WAVES * SCR_WAVE * 4;
+    // Epilogue scratch: none of its own.  Wave w is the only reader of the samples between what the wave before it
+    // reads into w's range (HALO samples) and the next wave's range, so once its matrix phase is over it may reuse
+    // that stretch of each plane: block b's accumulator tile goes to plane b there (SCR_WAVE floats each).
+    static constexpr int HALO = NCH * mf::CHUNK - (mf::SEGS * mf::SEG_OUT - mf::WAVE_NEW) * D - (mf::SEGS - 1) * 0;
+    static constexpr int OFF_ATAN = 4 * PL;
     static constexpr int OFF_MISC = OFF_ATAN + 256 * 8;
     static constexpr int LDS = OFF_MISC + 32;        // 4 wave maxima, the queue's hand-over slot
     static_assert((1 << LOGQ) == Q, "segment stride must be a power of two");
+    static_assert(HALO >= 0 && HALO % 32 == 0, "halo");
+    static_assert(mf::plane_pos(mf::WAVE_NEW * D - 1, D) + 2 - mf::plane_pos(HALO, D) >= SCR_WAVE * 4, "a wave's own stretch of a plane must hold one accumulator tile");
     static_assert(mf::ROUND % Q == 0, "a staging round must cover whole segment strides");
 };
 
@@ -158,7 +163,6 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
     constexpr int NTE = mf::NTE, BLK = mf::BLK, NBLK = mf::NBLK;
 
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
-    float *scr = reinterpret_cast<float *>(smem + G::OFF_SCR);
     const AtanPairs s_atan{reinterpret_cast<const f32x2 *>(smem + G::OFF_ATAN)};
     float *wmax = reinterpret_cast<float *>(smem + G::OFF_MISC);
     unsigned *sched_slot = reinterpret_cast<unsigned *>(smem + G::OFF_MISC + 16);
@@ -197,7 +201,9 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
     const int rd_u = w * (mf::WAVE_NEW * D) + (sl << LOGQ) + 8 * g;       // sample of chunk 0
     const int rd_plane = part * 2 * PL;
     // epilogue scratch: written in the accumulator layout, read as 2 consecutive outputs per lane
-    float *scw = scr + w * SCR_WAVE;
+    // (position of the first sample only this wave reads; every wave's range starts on a multiple of 32 samples)
+    const int scw_u = w * (mf::WAVE_NEW * D) + G::HALO;
+    float *scw = reinterpret_cast<float *>(smem + 2 * scw_u + 32 * (scw_u >> LOGQ));      // + b * PL bytes for block b
     const int sc_wr = sl * SCR_SEG + 8 * g + part;                      // + 2 i
     const int rsl = lane >> 3, r8 = lane & 7;
     const int sc_rd = rsl * SCR_SEG + 4 * r8;
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
     // allocation -- and that item is zeroed while staging (a 16-byte load at offset -8 would
     // be out of range as a whole).
     const int lead = a.off ^ (int)(a.n_lo & 1);
-    auto tile_geom = [&](int s, int b, __amdgpu_buffer_rsrc_t &rsrc, int &voff) {
+    auto tile_geom = [&](int s, int b, __amdgpu_buffer_rsrc_t &rsrc, int &voff) __attribute__((always_inline)) {
         const long long g0 = ((long long)b * NTE - BLK) * D - a.off - a.n_lo + lead;   // tile start relative to the descriptor
         const float2 *x = a.x + (long long)s * a.x_stride + a.n_lo - lead;
         const long long bytes = (a.n_in - a.n_lo + lead) * 8;
@@ -219,7 +225,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         voff = (int)(g0 * 8) + 16 * t;              // negative = before the stream: out of range, zeros
     };
     // part < 0: all rounds; else the part-th quarter
-    auto fetch = [&](__amdgpu_buffer_rsrc_t rsrc, int voff, int part_) {
+    auto fetch = [&](__amdgpu_buffer_rsrc_t rsrc, int voff, int part_) __attribute__((always_inline)) {
         constexpr int PER = (NI + 3) / 4;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -234,7 +240,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
     const unsigned total_tiles = (unsigned)tiles_per_stream * (unsigned)a.n_streams;
     const unsigned Gd = gridDim.x;
     unsigned cur = blockIdx.x, nxt = cur + Gd;
-    auto decode = [&](unsigned id, int &s_, int &b_) {
+    auto decode = [&](unsigned id, int &s_, int &b_) __attribute__((always_inline)) {
         b_ = (int)(id / (unsigned)a.n_streams);
         s_ = (int)(id - (unsigned)b_ * (unsigned)a.n_streams);
     };
@@ -293,6 +299,13 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
             for (int i = 0; i < NI; ++i)
                 if (voff_cur + i * (16 * mf::THREADS) == 0) { pf[i][0] = 0.f; pf[i][1] = 0.f; }
         }
+#if defined(GRHIP_DIAG) && defined(GRHIP_MF_EXP)      // timing experiments of diagnostic builds (wrong results): 2 = no staging,
+        const bool exp_off = a.n_out < 0;                  // 1 = no matrix phase / epilogue, 4 = no epilogue; never true at run time
+#define MF_EXP_SKIP(bit) if (!((GRHIP_MF_EXP & (bit)) && !exp_off))
+#else
+#define MF_EXP_SKIP(bit)
+#endif
+        MF_EXP_SKIP(2)
         {
             const f32x2 ws0 = wl * scale, ws1 = wl1 * scale;
             unsigned char *dst = smem + st_off;
@@ -354,39 +367,37 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         const int jt = w * mf::WAVE_NEW + rsl * mf::SEG_OUT + 2 * r8;
         const int n_base = bidx * NTE - BLK + jt;          // stream index of that output (block 0); < 2^28
         const bool first_of_stream = bidx == 0 && t == 7;   // lane (segment 0, rows 14/15) of wave 0
-        float2 y_pend = make_float2(0.f, 0.f);      // first output of the segment, waits for its predecessor
+        float ypendx = 0.f, ypendy = 0.f;           // first output of the segment, waits for its predecessor
         float d1_pend = 0.f;
-        float2 y1 = make_float2(0.f, 0.f);
+        float y1x = 0.f, y1y = 0.f;
+        const float ypfx = ypf.x, ypfy = ypf.y;
 
-        // one 16-output block: accumulator tile -> scratch -> two consecutive outputs per lane -> demodulator / store
-        auto epilogue = [&](int b, const f32x4 &accb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) scw[sc_wr + 2 * i] = accb[i];
-            asm volatile("" ::: "memory");          // (LDS executes a wave's operations in order; this orders the compiler)
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(scw + sc_rd);
-            asm volatile("" ::: "memory");
-            const float2 y0 = make_float2(v[0], v[1]);
-            const float2 y1_prev_block = y1;
-            y1 = make_float2(v[2], v[3]);
+        // one 16-output block: two consecutive outputs per lane (v: re0, im0, re1, im1) -> demodulator / store
+        // (plain floats for everything that is selected per lane: a select between members of two float2 objects
+        // becomes a select between their ADDRESSES, which pins both -- and every variable captured next to them --
+        // in scratch memory)
+        auto epilogue = [&](int b, const f32x4 &v) __attribute__((always_inline)) {
+            const float y0x = v[0], y0y = v[1];
+            const float y1px = y1x, y1py = y1y;          // previous block's second output
+            y1x = v[2]; y1y = v[3];
+            const float2 y0 = make_float2(y0x, y0y);
             const int n = n_base + BLK * b;
             const bool own = !(b == 0 && rsl == 0) && n >= 0;       // the wave's overlap block stores nothing
             if (DEMOD) {
                 if (b == 0) {
-                    y1.x = first_of_stream ? ypf.x : y1.x;
-                    y1.y = first_of_stream ? ypf.y : y1.y;
+                    y1x = first_of_stream ? ypfx : y1x;
+                    y1y = first_of_stream ? ypfy : y1y;
                 }
                 // predecessor of y0: the lane before (same segment), or the previous block's last output
-                float2 prev;
-                prev.x = dpp_row<0x111>(y1.x);      // row_shr:1
-                prev.y = dpp_row<0x111>(y1.y);
+                float px = dpp_row<0x111>(y1x), py = dpp_row<0x111>(y1y);      // row_shr:1
                 if (b > 0) {
-                    const float cx = dpp_row<0x107>(y1_prev_block.x);   // row_shl:7: lane + 7
-                    const float cy = dpp_row<0x107>(y1_prev_block.y);
-                    prev.x = r8 == 0 ? cx : prev.x;
-                    prev.y = r8 == 0 ? cy : prev.y;
+                    const float cx = dpp_row<0x107>(y1px), cy = dpp_row<0x107>(y1py);   // row_shl:7: lane + 7
+                    px = r8 == 0 ? cx : px;
+                    py = r8 == 0 ? cy : py;
                 } else {
-                    y_pend = y0;
+                    ypendx = y0x; ypendy = y0y;
                 }
+                const float2 prev = make_float2(px, py), y1 = make_float2(y1x, y1y);
                 const float d0 = quad_demod_fast(y0, prev, a.gain, s_atan);
                 const float d1 = quad_demod_fast(y1, y0, a.gain, s_atan);
                 if (b == 0) d1_pend = d1;
@@ -394,7 +405,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                 const f32x2 dd{d0, d1};
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, dd), orsrc, st_ok ? 4 * n : OOB, 0, 0);
             } else {
-                float2 o0 = y0, o1 = y1;
+                float2 o0 = y0, o1 = make_float2(y1x, y1y);
                 if (PREMIX) {
                     const float4 vv = *reinterpret_cast<const float4 *>(a.vtab + jt + BLK * b);   // e^{-jw j D}
                     o0 = cmul_fma(o0, make_float2(vv.x, vv.y));
@@ -407,10 +418,6 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                     o0 = cmul_ref(o0, make_float2(gq[0], gq[1]));                   // gr_rotator: z = in * d_phase
                     o1 = cmul_ref(o1, make_float2(gq[2], gq[3]));
                 }
-                // Two 8-byte stores, not one of 16: a store of more than 64 bits reads its data registers
-                // some time after it issues, and an MFMA issued behind it may already have rewritten them
-                // (measured: the compiler's wait states cover a vector-ALU writer only; one block in
-                // thirty came out with a stale real part).  Stores of up to 64 bits read at issue.
                 const f32x2 oa{o0.x, o0.y}, ob{o1.x, o1.y};
                 const int so = own ? 8 * n : OOB;
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oa), orsrc, so, 0, 0);
@@ -420,11 +427,19 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
 
         // ---- matrix phase, block by block (30 MFMAs each) ----
         // Operand chunks are read one chunk ahead of their use (an LDS round trip is ~100 cycles).
-        auto chunk_ptr = [&](int c) {
+        auto chunk_ptr = [&](int c) __attribute__((always_inline)) {
             const int u = rd_u + mf::CHUNK * c;
             return smem + rd_plane + 2 * u + 32 * (u >> LOGQ);
         };
         f32x4 acc[NBLK];
+#if defined(GRHIP_DIAG) && defined(GRHIP_MF_EXP) && (GRHIP_MF_EXP & 1)
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fetch(rsrc_n, voff_n, q);
+        if (exp_off)
+#endif
+        {
         h16x8 Bh_n = *reinterpret_cast<const h16x8 *>(chunk_ptr(0));
         h16x8 Bl_n = *reinterpret_cast<const h16x8 *>(chunk_ptr(0) + PL);
 #pragma unroll
@@ -445,7 +460,10 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                 if (j == 1) fetch(rsrc_n, voff_n, b);       // a quarter of the next tile's loads per block
             }
         }
+        }
         MF_STAMP(4);
+        MF_EXP_SKIP(5)
+        {
         // The epilogues run BEHIND the matrix phase, fenced off from it.  Letting hipcc 7.2 interleave
         // them with the MFMAs of the following block (it does so eagerly: the code is branch-free) bought
         // nothing (1.26 ms either way, same box) and, in the rotate epilogue, gave one 16-output block in
@@ -456,13 +474,33 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         // store of its result (mfma_lds_raw*.hip: 6 suffice, alone or beside an MFMA-issuing partner wave;
         // hipcc pads 8).  Unresolved; the fence costs nothing.
         __builtin_amdgcn_sched_barrier(0);
+        // all four accumulator tiles through the wave's own stretch of the planes in ONE round trip: accumulator layout
+        // in ([segment][row][re, im]), two consecutive complex outputs per lane out.  (LDS executes a wave's operations
+        // in order; the wavefront-scope fences order the compiler and emit nothing.)
 #pragma unroll
-        for (int b = 0; b < NBLK; ++b) epilogue(b, acc[b]);
+        for (int b = 0; b < NBLK; ++b) {
+            float *sb = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(scw) + b * PL);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sb[sc_wr + 2 * i] = acc[b][i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // block b+1 is read back while block b is demodulated (all four at once would not fit the register budget)
+        auto read_block = [&](int b) __attribute__((always_inline)) {
+            return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(scw) + b * PL + 4 * sc_rd);
+        };
+        f32x4 yv_n = read_block(0);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const f32x4 yv = yv_n;
+            if (b + 1 < NBLK) yv_n = read_block(b + 1);
+            epilogue(b, yv);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (DEMOD) {
             // first output of every segment but the wave's first: predecessor = last output of the
             // segment before, i.e. the second output of the lane before, after the last block
-            const float px = __shfl_up(y1.x, 1), py = __shfl_up(y1.y, 1);
-            const float dp = quad_demod_fast(y_pend, make_float2(px, py), a.gain, s_atan);
+            const float px = __shfl_up(y1x, 1), py = __shfl_up(y1y, 1);
+            const float dp = quad_demod_fast(make_float2(ypendx, ypendy), make_float2(px, py), a.gain, s_atan);
             const bool st_ok = r8 == 0 && rsl != 0 && n_base >= 0;
             const f32x2 dd{dp, d1_pend};
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, dd), orsrc, st_ok ? 4 * n_base : OOB, 0, 0);
@@ -487,6 +525,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
             }
         }
 
+        }
         MF_STAMP(5);
         cur = nxt;
         if (!a.sched) nxt = nxt + Gd;
