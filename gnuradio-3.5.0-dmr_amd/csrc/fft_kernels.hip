@@ -140,38 +140,57 @@ __device__ __forceinline__ float2 cmul2(float2 a, float2 b)
     return make_float2(r.x, r.y);
 }
 
-// DFT of 4 points in place (forward: W4 = -i)
+// a + (-i) b and a + (+i) b in one packed instruction: the halves of b are routed with op_sel, the sign is an operand modifier
+__device__ __forceinline__ f32x2_t add_mi(f32x2_t a, f32x2_t b)
+{
+    f32x2_t r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));     // (a.x + b.y, a.y - b.x)
+    return r;
+}
+__device__ __forceinline__ f32x2_t add_pi(f32x2_t a, f32x2_t b)
+{
+    f32x2_t r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));     // (a.x - b.y, a.y + b.x)
+    return r;
+}
+
+// DFT of 4 points in place (forward: W4 = -i): eight packed additions
+template <bool FWD>
+__device__ __forceinline__ void radix4(f32x2_t &a, f32x2_t &b, f32x2_t &c, f32x2_t &d)
+{
+    const f32x2_t s0 = a + c, d0 = a - c, s1 = b + d, d1 = b - d;
+    a = s0 + s1;
+    c = s0 - s1;
+    b = FWD ? add_mi(d0, d1) : add_pi(d0, d1);          // d0 -/+ i d1
+    d = FWD ? add_pi(d0, d1) : add_mi(d0, d1);
+}
 template <bool FWD>
 __device__ __forceinline__ void radix4(float2 &a, float2 &b, float2 &c, float2 &d)
 {
-    const float2 s0 = c_add(a, c), d0 = c_sub(a, c), s1 = c_add(b, d), d1 = c_sub(b, d);
-    const float2 r = FWD ? make_float2(d1.y, -d1.x) : make_float2(-d1.y, d1.x);     // -/+ i (b - d)
-    a = c_add(s0, s1);
-    b = c_add(d0, r);
-    c = c_sub(s0, s1);
-    d = c_sub(d0, r);
+    f32x2_t A{a.x, a.y}, B{b.x, b.y}, C{c.x, c.y}, D{d.x, d.y};
+    radix4<FWD>(A, B, C, D);
+    a = make_float2(A.x, A.y); b = make_float2(B.x, B.y); c = make_float2(C.x, C.y); d = make_float2(D.x, D.y);
 }
 
 // v[m] <- sum_n v[n] W16^{nm}, n = c + 4d, m = r + 4s
 template <bool FWD>
-__device__ __forceinline__ void dft16(float2 (&v)[16])
+__device__ __forceinline__ void dft16(f32x2_t (&v)[16])
 {
 #pragma unroll
     for (int c = 0; c < 4; ++c) radix4<FWD>(v[c], v[c + 4], v[c + 8], v[c + 12]);    // v[c + 4r] = a[c][r]
     const float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
     const float sg = FWD ? -1.f : 1.f;
-    const float2 w1 = make_float2(C1, sg * S1), w2 = make_float2(H, sg * H), w3 = make_float2(S1, sg * C1);
-    const float2 w6 = make_float2(-H, sg * H), w9 = make_float2(-C1, -sg * S1);
+    const f32x2_t w1{C1, sg * S1}, w2{H, sg * H}, w3{S1, sg * C1}, w6{-H, sg * H}, w9{-C1, -sg * S1};
     // a[c][r] *= W16^{c r}
-    v[1 + 4] = cmul2(v[1 + 4], w1);
-    v[1 + 8] = cmul2(v[1 + 8], w2);
-    v[1 + 12] = cmul2(v[1 + 12], w3);
-    v[2 + 4] = cmul2(v[2 + 4], w2);
-    v[2 + 8] = FWD ? make_float2(v[2 + 8].y, -v[2 + 8].x) : make_float2(-v[2 + 8].y, v[2 + 8].x);   // W16^4 = -/+ i
-    v[2 + 12] = cmul2(v[2 + 12], w6);
-    v[3 + 4] = cmul2(v[3 + 4], w3);
-    v[3 + 8] = cmul2(v[3 + 8], w6);
-    v[3 + 12] = cmul2(v[3 + 12], w9);
+    v[1 + 4] = cmul_pk(v[1 + 4], w1);
+    v[1 + 8] = cmul_pk(v[1 + 8], w2);
+    v[1 + 12] = cmul_pk(v[1 + 12], w3);
+    v[2 + 4] = cmul_pk(v[2 + 4], w2);
+    v[2 + 8] = FWD ? f32x2_t{v[2 + 8].y, -v[2 + 8].x} : f32x2_t{-v[2 + 8].y, v[2 + 8].x};   // W16^4 = -/+ i
+    v[2 + 12] = cmul_pk(v[2 + 12], w6);
+    v[3 + 4] = cmul_pk(v[3 + 4], w3);
+    v[3 + 8] = cmul_pk(v[3 + 8], w6);
+    v[3 + 12] = cmul_pk(v[3 + 12], w9);
 #pragma unroll
     for (int r = 0; r < 4; ++r) radix4<FWD>(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);  // v[4r + s] = X[r + 4s]
     // un-permute: X[m], m = r + 4s, sits at 4r + s
@@ -179,78 +198,149 @@ __device__ __forceinline__ void dft16(float2 (&v)[16])
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int s2 = r + 1; s2 < 4; ++s2) {
-            const float2 tmp = v[4 * r + s2];
+            const f32x2_t tmp = v[4 * r + s2];
             v[4 * r + s2] = v[4 * s2 + r];
             v[4 * s2 + r] = tmp;
         }
 }
-
 template <bool FWD>
-__global__ void __launch_bounds__(256, 4)
-fft4096_kernel(int shift, const float *__restrict__ window, const float2 *__restrict__ twiddle,
-               const float2 *__restrict__ in, float2 *__restrict__ out)
+__device__ __forceinline__ void dft16(float2 (&v)[16])
+{
+    f32x2_t u[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u[i] = f32x2_t{v[i].x, v[i].y};
+    dft16<FWD>(u);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = make_float2(u[i].x, u[i].y);
+}
+
+// MODE bit 0: window on the way in; bit 1: shift (forward: fftshift on the way out; backward and no window: ifftshift on
+// the way in -- both are "point q <-> point q ^ 8" of the same lane, a renaming of registers).
+// Persistent workgroups (four per CU) walk the vectors: the twiddles of the last pass (W_N^{t q}: fifteen per lane) stay in
+// registers and those of the middle pass (W_256^{k q}: 256 values) in LDS for the whole launch instead of being fetched
+// per vector, and the next vector's sixteen points are requested as soon as the first pass has left its registers, so that
+// HBM latency runs under passes 2 and 3 and the stores.
+// (the window's sixteen values per lane are resident too: three workgroups per CU then, four otherwise)
+constexpr int fft4096_wg_per_cu(int mode) { return (mode & 1) ? 3 : 4; }
+template <bool FWD, int MODE>
+__global__ void __launch_bounds__(256, fft4096_wg_per_cu(MODE))
+fft4096_kernel(const float *__restrict__ window, const float2 *__restrict__ twiddle,
+               const float2 *__restrict__ in, float2 *__restrict__ out, int nvec)
 {
     constexpr int N = 4096;
-    __shared__ float2 S[N + N / 16];
-    auto pad = [](int i) { return i + (i >> 4); };
+    __shared__ f32x2_t S[N + N / 16];
+    __shared__ f32x2_t W2[16 * 17];                         // [k][q], rows skewed by one slot: 16 rows on 16 bank pairs
+    // slot of element i is i + (i >> 4) (one pad slot per 16).  Written out per access pattern -- 17 t + m, (t + (t >> 4)) +
+    // 272 q, (j + (j >> 4)) + 17 m -- so that each pattern is one base register and immediate offsets
     const int t = threadIdx.x;
-    const float2 *__restrict__ x = in + (long long)blockIdx.x * N;
-    float2 *__restrict__ y = out + (long long)blockIdx.x * N;
-    float2 v[16];
+    constexpr bool WIN = MODE & 1, SHIFT = MODE & 2;
+    constexpr int SW_IN = (!FWD && SHIFT && !WIN) ? 8 : 0, SW_OUT = (FWD && SHIFT) ? 8 : 0;
 
-    // ---- pass 1 (p = 1): points straight from HBM (gr_fft_vcc_fftw.cc:68-83)
+    f32x2_t w3[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int i = t + 256 * q;
-        if (window) {
-            const float2 a = x[i];
-            const float w = window[i];
-            v[q] = make_float2(a.x * w, a.y * w);
-        } else if (!FWD && shift) {
-            v[q] = x[(i + N / 2) & (N - 1)];          // dst[k] = in[(k + N/2) mod N]
-        } else {
-            v[q] = x[i];
-        }
-    }
-    dft16<FWD>(v);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) S[pad(16 * t + m)] = v[m];
-    __syncthreads();
-
-    // ---- pass 2 (p = 16): twiddle W_256^{k q} = W_N^{16 k q}
+    for (int q = 1; q < 16; ++q) { const float2 w = tw<FWD>(twiddle, t * q); w3[q] = f32x2_t{w.x, w.y}; }
     {
-        const int k = t & 15;
-        float2 w[16];
+        const float2 w = tw<FWD>(twiddle, 16 * (t >> 4) * (t & 15));
+        W2[(t >> 4) * 17 + (t & 15)] = f32x2_t{w.x, w.y};              // visible after the loop's first barrier
+    }
+    float wn[16];
+    if (WIN) {
 #pragma unroll
-        for (int q = 1; q < 16; ++q) w[q] = tw<FWD>(twiddle, 16 * k * q);
+        for (int q = 0; q < 16; ++q) wn[q] = window[t + 256 * q];
+    }
+
+    // vectors through raw buffer descriptors (wave-uniform base in SGPRs, one lane offset, the point's stride as the
+    // instruction's scalar offset): no 64-bit address registers beside the thirty-two points in flight
+    typedef unsigned int fft_u32x2 __attribute__((ext_vector_type(2)));
+    f32x2_t pre[16];
+    auto request = [&](int vec) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in + (long long)vec * N), 0, N * 8, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = S[pad(t + 256 * q)];
-        __syncthreads();                               // every lane has read before anyone writes
+        for (int q = 0; q < 16; ++q) {      // dst[k] = in[(k + N/2) mod N] when shifting
+            // (bit-cast the whole vector: clang's __builtin_bit_cast of a vector ELEMENT reads element 0)
+            pre[q] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, 8 * t, 2048 * (q ^ SW_IN), 0));
+        }
+    };
+    int vec = blockIdx.x;
+    if (vec < nvec) request(vec);
+    for (; vec < nvec; vec += gridDim.x) {
+        f32x2_t v[16];
+        // ---- pass 1 (p = 1): points straight from HBM (gr_fft_vcc_fftw.cc:68-83)
 #pragma unroll
-        for (int q = 1; q < 16; ++q) v[q] = cmul2(v[q], w[q]);
+        for (int q = 0; q < 16; ++q) v[q] = WIN ? pre[q] * wn[q] : pre[q];
         dft16<FWD>(v);
-        const int j = (t - k) * 16 + k;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) S[pad(j + 16 * m)] = v[m];
+        for (int m = 0; m < 16; ++m) S[17 * t + m] = v[m];
         __syncthreads();
-    }
+#ifndef GRHIP_FFT_NOPRE
+        if (vec + (int)gridDim.x < nvec) request(vec + gridDim.x);
+#endif
 
-    // ---- pass 3 (p = 256): twiddle W_N^{t q}; results straight to HBM (gr_fft_vcc_fftw.cc:89-96)
-    {
-        float2 w[16];
+        // ---- pass 2 (p = 16): twiddle W_256^{k q} = W_N^{16 k q}
+        {
+            const int k = t & 15;
 #pragma unroll
-        for (int q = 1; q < 16; ++q) w[q] = tw<FWD>(twiddle, t * q);
+            for (int q = 0; q < 16; ++q) v[q] = S[t + (t >> 4) + 272 * q];
+            __syncthreads();                               // every lane has read before anyone writes
+            // (two table reads at a time: all fifteen hoisted would cost thirty registers beside the points in flight)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = S[pad(t + 256 * q)];
+            for (int q0 = 0; q0 < 16; q0 += 2) {
 #pragma unroll
-        for (int q = 1; q < 16; ++q) v[q] = cmul2(v[q], w[q]);
-        dft16<FWD>(v);
+                for (int q = q0 ? q0 : 1; q < q0 + 2; ++q) v[q] = cmul_pk(v[q], W2[k * 17 + q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            dft16<FWD>(v);
+            const int j = (t - k) * 16 + k;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int idx = t + 256 * m;
-            // forward + shift: out[k] = fft[(k + N/2) mod N]
-            y[(FWD && shift) ? ((idx + N / 2) & (N - 1)) : idx] = v[m];
+            for (int m = 0; m < 16; ++m) S[j + (j >> 4) + 17 * m] = v[m];
+            __syncthreads();
         }
+
+        // ---- pass 3 (p = 256): twiddle W_N^{t q}; results straight to HBM (gr_fft_vcc_fftw.cc:89-96)
+        {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = S[t + (t >> 4) + 272 * q];
+            __syncthreads();                               // S belongs to the next vector from here
+#pragma unroll
+            for (int q = 1; q < 16; ++q) v[q] = cmul_pk(v[q], w3[q]);
+            dft16<FWD>(v);
+#ifdef GRHIP_FFT_NOPRE
+            if (vec + (int)gridDim.x < nvec) request(vec + gridDim.x);
+#endif
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(out + (long long)vec * N, 0, N * 8, 0x00020000);
+#pragma unroll
+            for (int m = 0; m < 16; ++m)        // out[k] = fft[(k + N/2) mod N] when shifting
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fft_u32x2, v[m]), r, 8 * t, 2048 * (m ^ SW_OUT), 0);
+        }
+    }
+}
+
+static int fft_num_cus()
+{
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 0;
+        n_cus = n > 0 ? n : 256;
+    }
+    return n_cus;
+}
+
+template <bool FWD>
+static void launch_fft4096(int shift, const float *window, const float2 *twiddle, const float2 *in, float2 *out,
+                           long long nvec, hipStream_t st)
+{
+    // at most 2^31 - 1 vectors per launch (8 TB of samples): the caller's sizes are far below
+    const int nv = (int)nvec;
+    const int mode = (window ? 1 : 0) | (shift ? 2 : 0);
+    const long long cap = (long long)fft4096_wg_per_cu(mode) * fft_num_cus();
+    const dim3 grid((unsigned)(nvec < cap ? nvec : cap));
+    switch (mode) {
+    case 0: hipLaunchKernelGGL((fft4096_kernel<FWD, 0>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    case 1: hipLaunchKernelGGL((fft4096_kernel<FWD, 1>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    case 2: hipLaunchKernelGGL((fft4096_kernel<FWD, 2>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    default: hipLaunchKernelGGL((fft4096_kernel<FWD, 3>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
     }
 }
 
@@ -260,8 +350,9 @@ int launch_fft(int N, int forward, int shift, const float *window, const float2 
     if (nvec <= 0) return GRHIP_OK;
     if (!fft_size_supported(N)) return fail(GRHIP_EINVAL, "fft size %d not supported on device", N);
     if (N == 4096) {
-        if (forward) hipLaunchKernelGGL(fft4096_kernel<true>, dim3((unsigned)nvec), dim3(256), 0, st, shift, window, twiddle, in, out);
-        else hipLaunchKernelGGL(fft4096_kernel<false>, dim3((unsigned)nvec), dim3(256), 0, st, shift, window, twiddle, in, out);
+        if (nvec > 0x7fffffffLL) return fail(GRHIP_EINVAL, "fft: too many vectors in one call");
+        if (forward) launch_fft4096<true>(shift, window, twiddle, in, out, nvec, st);
+        else launch_fft4096<false>(shift, window, twiddle, in, out, nvec, st);
         GRHIP_HIP(hipGetLastError());
         return GRHIP_OK;
     }

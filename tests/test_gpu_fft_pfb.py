@@ -57,6 +57,20 @@ def test_fft_window_and_shift(gpu, po, forward, shift, win, N, nvec):
     assert blk.set_window(np.ones(N, np.float32)) is True
 
 
+@pytest.mark.parametrize("forward,shift,win", [(True, False, False), (False, True, False), (True, True, True)])
+def test_fft4096_persistent_walk(gpu, po, forward, shift, win):
+    """more vectors than resident workgroups (4 per CU plain, 3 windowed): every workgroup walks several vectors with the
+    next one's points in flight, a ragged last round; every vector against the oracle"""
+    rng = np.random.default_rng(11)
+    N, nvec = 4096, 2100
+    x = _rc(rng, N * nvec)
+    w = np.hamming(N).astype(np.float32) if win else None
+    ref = po.fft_vcc(N, forward, w, shift, x)
+    got = gpu.fft_vcc(N, forward, w if win else [], shift).work(nvec, x)
+    err = np.abs(got - ref).reshape(nvec, N).max(1) / np.abs(ref).reshape(nvec, N).max(1)
+    assert err.max() <= 1e-5, (int(err.argmax()), float(err.max()))
+
+
 def test_fft_linearity_and_parseval_full_size(gpu):
     """size-independent properties at the BASELINE size (4096-pt, 4096 vectors = 2^24 samples)"""
     rng = np.random.default_rng(9)

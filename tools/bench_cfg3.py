@@ -46,18 +46,23 @@ def report(name, ms, items, bytes_per_item, unit="Msamples/s"):
 
 rng = np.random.default_rng(0)
 
-# cfg3: fft_vcc 4096-pt over 2^24 samples; pfb_channelizer M=8, 256-tap prototype, 2^24 samples
-N, nvec = 4096, 4096
-xv = torch.randn((N * nvec, 2), device=dev)
-yv = torch.empty((N * nvec, 2), device=dev)
-ff = g.fft_vcc(N, True, [], False)
-report("fft_vcc 4096-pt x 4096", timeit(lambda: ff.work_device(nvec, xv, yv, st)), N * nvec, 16)
-M, nout = 8, (1 << 24) // 8
-taps = wl.lowpass_taps(256, 0.5 / M, 1.0)
-pf = g.pfb_channelizer_ccf(M, taps, 1.0)
-per = nout + 64
-xs = torch.randn((M * per, 2), device=dev)
-yo = torch.empty((nout * M, 2), device=dev)
-pf.general_work_device(nout, xs, per, yo, st)       # first call returns 0 (d_updated)
-report("pfb_channelizer_ccf M=8 256t", timeit(lambda: pf.general_work_device(nout, xs, per, yo, st)), nout * M, 16)
+# cfg3: fft_vcc 4096-pt and pfb_channelizer M=8 (256-tap prototype) over 2^24 samples (268 MB of traffic: about the size
+# of the part's last-level cache, a 60 us kernel) and over 2^27 (2.1 GB: steady state against HBM)
+sizes = [int(a) for a in sys.argv[1:]] or [24, 27]
+for lg in sizes:
+    N, nvec = 4096, (1 << lg) // 4096
+    xv = torch.randn((N * nvec, 2), device=dev)
+    yv = torch.empty((N * nvec, 2), device=dev)
+    ff = g.fft_vcc(N, True, [], False)
+    report("fft_vcc 4096-pt x %d (2^%d samples)" % (nvec, lg), timeit(lambda: ff.work_device(nvec, xv, yv, st)), N * nvec, 16)
+    del xv, yv
+    M, nout = 8, (1 << lg) // 8
+    taps = wl.lowpass_taps(256, 0.5 / M, 1.0)
+    pf = g.pfb_channelizer_ccf(M, taps, 1.0)
+    per = nout + 64
+    xs = torch.randn((M * per, 2), device=dev)
+    yo = torch.empty((nout * M, 2), device=dev)
+    pf.general_work_device(nout, xs, per, yo, st)       # first call returns 0 (d_updated)
+    report("pfb_channelizer_ccf M=8 256t (2^%d samples)" % lg, timeit(lambda: pf.general_work_device(nout, xs, per, yo, st)), nout * M, 16)
+    del xs, yo
 
