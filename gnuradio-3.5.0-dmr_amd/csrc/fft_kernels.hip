@@ -465,129 +465,197 @@ pfb_kernel(const PfbArgs a)
 // ---------------------------------------------------------------------------
 typedef const float __attribute__((address_space(4))) *pfb_cfloat_p;
 
-template <int M>
-__global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a)
+// Persistent workgroups walk the tiles.  NT = padded taps per filter / 8: for NT in 1..4 the wave's taps are read once
+// per launch and stay in SGPRs, the FIR is straight-line code and the tile's 512 + 8 NT samples per stream are nine
+// 64-lane rounds of range-checked buffer loads (no branches); NT = 0 takes any length with the taps read in the loop.
+template <int M, int NT>
+__global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a, long long ntiles)
 {
     constexpr int R = 8, TT = 64 * R;                  // output vectors per tile
     constexpr int LOGM = M == 1 ? 0 : M == 2 ? 1 : M == 4 ? 2 : M == 8 ? 3 : 4;
     static_assert((1 << LOGM) == M, "M must be a power of two <= 16");
+    typedef float pfb_f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int pfb_u32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tpfp = (a.tpf + R - 1) / R * R;          // taps padded to a multiple of R (zeros)
+    const int tpfp = NT ? R * NT : (a.tpf + R - 1) / R * R;    // taps padded to a multiple of R (zeros)
     const int XS = (TT + tpfp + R) + (TT + tpfp + R) / R + 1;   // slots per stream, padded
     const int SS = TT + TT / R + 1;                    // slots per IFFT input row, padded
-    float2 *xs = (float2 *)smem;                       // [M][XS]
-    float2 *sl = xs;                                   // [M][SS], SS < XS: reuses the sample buffer once every
+    pfb_f32x2 *xs = (pfb_f32x2 *)smem;                 // [M][XS]
+    pfb_f32x2 *sl = xs;                                // [M][SS], SS < XS: reuses the sample buffer once every
                                                        // wave is done with its FIR (40 KB instead of 77 KB: 3 workgroups per CU)
-    const int t = threadIdx.x, j = t >> 6, ln = t & 63;
-    const long long t0 = (long long)blockIdx.x * TT;
+    const int t = threadIdx.x, ln = t & 63;
+    const int j = __builtin_amdgcn_readfirstlane(t >> 6);      // wave = stream: descriptors and taps stay scalar
     const pfb_cfloat_p taps = (pfb_cfloat_p)(a.ftaps) + (size_t)(M - 1 - j) * a.tpf;
     const pfb_cfloat_p dft = (pfb_cfloat_p)(a.dft);
-
-    // ---- stage stream j: items in_j[t0+1 .. t0+TT+tpfp]; readable range is [0, nout+tpf]
-    {
-        const float2 *x = a.in + (long long)j * a.stride;
-        const long long lim = a.nout + a.tpf;          // tpf history items + nout new ones per stream
-        float2 *dst = xs + (size_t)j * XS;
-        // eight independent loads in flight per lane (one load per loop trip would leave the wave waiting for
-        // HBM latency nine times per tile)
-        const int tot = TT + tpfp;
-        for (int mb = ln; mb < tot; mb += 64 * 8) {
-            float2 v[8];
+    float hres[NT ? R * NT : 1];
+    if (NT) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = mb + 64 * i;
-                const long long g = t0 + 1 + m;
-                v[i] = make_float2(0.f, 0.f);
-                if (m < tot && g < lim) v[i] = x[g];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = mb + 64 * i;
-                if (m < tot) dst[m + (m >> 3)] = v[i];
-            }
-        }
+        for (int i = 0; i < R * NT; ++i) hres[i] = i < a.tpf ? taps[i] : 0.f;
     }
-    __builtin_amdgcn_s_waitcnt(0);                     // wave-private region: no workgroup barrier needed
-    __builtin_amdgcn_wave_barrier();
+    // stream j: tpf history items + nout new ones; past that the range check returns zeros (and moves no bytes)
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.in + (long long)j * a.stride), 0,
+                                                                        (int)((a.nout + a.tpf) * 8), 0x00020000);
+    constexpr int OOB = (int)0xfffffff0;
+    const int tot = TT + tpfp;
+    pfb_f32x2 *dst = xs + (size_t)j * XS;
+    const pfb_f32x2 *xp = xs + (size_t)j * XS + ln * R + ln;      // slot of m = 8 ln
 
-    // ---- FIR, 8 output vectors per lane
-    // (re, im) pairs as 2-vectors: one v_pk_fma_f32 per tap and output instead of two v_fma_f32
-    typedef float pfb_f32x2 __attribute__((ext_vector_type(2)));
-    pfb_f32x2 accv[R];
+    // (NT > 0) the next tile's samples are requested as soon as this tile's have left their registers for LDS: HBM latency
+    // runs under the FIR, the DFT and the stores
+    constexpr int NR = NT ? (TT + R * NT + 63) / 64 : 1;
+    pfb_f32x2 pv[NR];
+    auto request = [&](long long tile_) __attribute__((always_inline)) {
+        const int vb = (int)((tile_ * TT + 1) * 8) + 8 * ln;
 #pragma unroll
-    for (int r = 0; r < R; ++r) accv[r] = (pfb_f32x2){0.f, 0.f};
-    {
-        const float2 *xp = xs + (size_t)j * XS + ln * R + ln;      // slot of m = 8 ln
-        pfb_f32x2 w[R];
+        for (int i = 0; i < NR; ++i) {
+            const int m = ln + 64 * i;
+            pv[i] = __builtin_bit_cast(pfb_f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, m < tot ? vb + 512 * i : OOB, 0, 0));
+        }
+    };
+    if (NT && (long long)blockIdx.x < ntiles) request(blockIdx.x);
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long t0 = tile * TT;
+        // ---- stage stream j: items in_j[t0+1 .. t0+TT+tpfp]
+        const int vbase = (int)((t0 + 1) * 8) + 8 * ln;
+        if (NT) {
 #pragma unroll
-        for (int q = 0; q < R; ++q) { const float2 v = xp[q]; w[q] = (pfb_f32x2){v.x, v.y}; }
-        for (int q0 = 0; q0 < tpfp; q0 += R) {
-            const int nxt = q0 + R + (q0 >> 3) + 1;
-#pragma unroll
-            for (int qq = 0; qq < R; ++qq) {
-                const float h = (q0 + qq < a.tpf) ? taps[q0 + qq] : 0.f;
-                const pfb_f32x2 hv = (pfb_f32x2){h, h};
-#pragma unroll
-                for (int r = 0; r < R; ++r) accv[r] = __builtin_elementwise_fma(hv, w[(qq + r) & (R - 1)], accv[r]);
-                const float2 v = xp[nxt + qq];
-                w[qq] = (pfb_f32x2){v.x, v.y};
+            for (int i = 0; i < NR; ++i) {
+                const int m = ln + 64 * i;
+                if (m < tot) dst[m + (m >> 3)] = pv[i];
             }
-        }
-    }
-    float2 acc[R];
+            if (tile + gridDim.x < ntiles) request(tile + gridDim.x);
+        } else {
+            // eight independent loads in flight per lane
+            for (int mb = ln; mb < tot; mb += 64 * 8) {
+                pfb_f32x2 pv[8];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = make_float2(accv[r].x, accv[r].y);
-    // ---- to IFFT slot M-1-j, transposed: sl[slot][t_local]
-    __syncthreads();                                   // sl aliases xs
-    {
-        float2 *row = sl + (size_t)(M - 1 - j) * SS + ln * R + ln;
+                for (int i = 0; i < 8; ++i) {
+                    const int m = mb + 64 * i;
+                    pv[i] = __builtin_bit_cast(pfb_f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, m < tot ? vbase + 8 * (mb - ln) + 512 * i : OOB, 0, 0));
+                }
 #pragma unroll
-        for (int r = 0; r < R; ++r) row[r] = acc[r];
-    }
-    __syncthreads();
-
-    // ---- M-point backward DFT (unnormalised), one output vector per lane
-    for (int tl = t; tl < TT; tl += 64 * M) {
-        const long long tt = t0 + tl;
-        if (tt >= a.nout) continue;
-        float2 v[M];
-        // bit-reversed load, then radix-2 decimation-in-time stages
-#pragma unroll
-        for (int s = 0; s < M; ++s) {
-            int rv = 0;
-#pragma unroll
-            for (int bit = 0; bit < LOGM; ++bit)
-                if (s & (1 << bit)) rv |= (M >> 1) >> bit;
-            v[rv] = sl[(size_t)s * SS + tl + (tl >> 3)];
-        }
-        // (canonical loop bounds everywhere: anything the compiler cannot unroll turns v[] into
-        // a scratch array)
-#pragma unroll
-        for (int stg = 0; stg < LOGM; ++stg) {
-            const int len = 2 << stg;
-            const int half = len >> 1, step = M / len;
-#pragma unroll
-            for (int s0 = 0; s0 < M; s0 += len) {
-#pragma unroll
-                for (int k = 0; k < half; ++k) {
-                    const float wr = dft[2 * (k * step)], wi = dft[2 * (k * step) + 1];   // e^{+2 pi i k/len}
-                    const float2 u = v[s0 + k], q = v[s0 + k + half];
-                    const float2 tw = (k == 0) ? q : make_float2(__builtin_fmaf(q.x, wr, -(q.y * wi)),
-                                                                 __builtin_fmaf(q.x, wi, q.y * wr));
-                    v[s0 + k] = make_float2(u.x + tw.x, u.y + tw.y);
-                    v[s0 + k + half] = make_float2(u.x - tw.x, u.y - tw.y);
+                for (int i = 0; i < 8; ++i) {
+                    const int m = mb + 64 * i;
+                    if (m < tot) dst[m + (m >> 3)] = pv[i];
                 }
             }
         }
-        float2 *o = a.out + tt * M;
-        if (M >= 2) {
-            float4 *o4 = reinterpret_cast<float4 *>(o);
+        // (wave-private region: no workgroup barrier needed; the compiler's own waits order the LDS stores and reads of a lane,
+        // the wave barrier keeps it from moving one lane's reads above another lane's stores)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- FIR, 8 output vectors per lane: an 8-deep register window slides over the samples,
+        // (re, im) pairs as 2-vectors: one v_pk_fma_f32 per tap and output
+        pfb_f32x2 accv[R];
 #pragma unroll
-            for (int k = 0; k < M; k += 2) o4[k >> 1] = make_float4(v[k].x, v[k].y, v[k + 1].x, v[k + 1].y);
-        } else {
-            o[0] = v[0];
+        for (int r = 0; r < R; ++r) accv[r] = (pfb_f32x2){0.f, 0.f};
+        {
+            pfb_f32x2 w[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) w[q] = xp[q];
+            if (NT) {
+#pragma unroll
+                for (int q0 = 0; q0 < R * NT; q0 += R) {
+                    const int nxt = q0 + R + (q0 >> 3) + 1;
+#pragma unroll
+                    for (int qq = 0; qq < R; ++qq) {
+                        const float h = hres[q0 + qq];
+                        const pfb_f32x2 hv = (pfb_f32x2){h, h};
+#pragma unroll
+                        for (int r = 0; r < R; ++r) accv[r] = __builtin_elementwise_fma(hv, w[(qq + r) & (R - 1)], accv[r]);
+                        w[qq] = xp[nxt + qq];
+                    }
+                }
+            } else {
+                for (int q0 = 0; q0 < tpfp; q0 += R) {
+                    const int nxt = q0 + R + (q0 >> 3) + 1;
+#pragma unroll
+                    for (int qq = 0; qq < R; ++qq) {
+                        const float h = (q0 + qq < a.tpf) ? taps[q0 + qq] : 0.f;
+                        const pfb_f32x2 hv = (pfb_f32x2){h, h};
+#pragma unroll
+                        for (int r = 0; r < R; ++r) accv[r] = __builtin_elementwise_fma(hv, w[(qq + r) & (R - 1)], accv[r]);
+                        w[qq] = xp[nxt + qq];
+                    }
+                }
+            }
         }
+        // ---- to IFFT slot M-1-j, transposed: sl[slot][t_local]
+        __syncthreads();                               // sl aliases xs
+        {
+            pfb_f32x2 *row = sl + (size_t)(M - 1 - j) * SS + ln * R + ln;
+#pragma unroll
+            for (int r = 0; r < R; ++r) row[r] = accv[r];
+        }
+        __syncthreads();
+
+        // ---- M-point backward DFT (unnormalised), one output vector per lane
+        for (int tl = t; tl < TT; tl += 64 * M) {
+            const long long tt = t0 + tl;
+            if (tt >= a.nout) continue;
+            float2 v[M];
+            // bit-reversed load, then radix-2 decimation-in-time stages
+#pragma unroll
+            for (int s = 0; s < M; ++s) {
+                int rv = 0;
+#pragma unroll
+                for (int bit = 0; bit < LOGM; ++bit)
+                    if (s & (1 << bit)) rv |= (M >> 1) >> bit;
+                const pfb_f32x2 u = sl[(size_t)s * SS + tl + (tl >> 3)];
+                v[rv] = make_float2(u.x, u.y);
+            }
+            // (canonical loop bounds everywhere: anything the compiler cannot unroll turns v[] into
+            // a scratch array)
+#pragma unroll
+            for (int stg = 0; stg < LOGM; ++stg) {
+                const int len = 2 << stg;
+                const int half = len >> 1, step = M / len;
+#pragma unroll
+                for (int s0 = 0; s0 < M; s0 += len) {
+#pragma unroll
+                    for (int k = 0; k < half; ++k) {
+                        const float wr = dft[2 * (k * step)], wi = dft[2 * (k * step) + 1];   // e^{+2 pi i k/len}
+                        const float2 u = v[s0 + k], q = v[s0 + k + half];
+                        const float2 tw = (k == 0) ? q : make_float2(__builtin_fmaf(q.x, wr, -(q.y * wi)),
+                                                                     __builtin_fmaf(q.x, wi, q.y * wr));
+                        v[s0 + k] = make_float2(u.x + tw.x, u.y + tw.y);
+                        v[s0 + k + half] = make_float2(u.x - tw.x, u.y - tw.y);
+                    }
+                }
+            }
+            float2 *o = a.out + tt * M;
+            if (M >= 2) {
+                float4 *o4 = reinterpret_cast<float4 *>(o);
+#pragma unroll
+                for (int k = 0; k < M; k += 2) o4[k >> 1] = make_float4(v[k].x, v[k].y, v[k + 1].x, v[k + 1].y);
+            } else {
+                o[0] = v[0];
+            }
+        }
+        __syncthreads();                               // sl (= xs) belongs to the next tile's samples from here
     }
+}
+
+template <int M, int NT>
+static int launch_pfb_os1_nt(const PfbArgs &a, size_t lds, hipStream_t st)
+{
+    const int TT = 512;
+    static size_t cfg = 0;
+    if (lds > 48 * 1024 && lds > cfg) {
+        GRHIP_HIP(hipFuncSetAttribute((const void *)pfb_os1_kernel<M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cfg = lds;
+    }
+    const long long ntiles = (a.nout + TT - 1) / TT;
+    int per_cu = 0;                                    // resident workgroups per CU (registers and LDS both count)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfb_os1_kernel<M, NT>, 64 * M, lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    const long long cap = (long long)per_cu * fft_num_cus();
+    hipLaunchKernelGGL((pfb_os1_kernel<M, NT>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(64 * M), lds, st, a, ntiles);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
 }
 
 template <int M>
@@ -596,19 +664,16 @@ static int launch_pfb_os1(const PfbArgs &a, hipStream_t st)
     const int R = 8, TT = 512;
     const int tpfp = (a.tpf + R - 1) / R * R;
     const int XS = (TT + tpfp + R) + (TT + tpfp + R) / R + 1;
-    const int SS = TT + TT / R + 1;
-    (void)SS;
-    size_t lds = (size_t)M * XS * sizeof(float2);
+    const size_t lds = (size_t)M * XS * sizeof(float2);
     if (lds > 150 * 1024) return -1;
-    static size_t cfg = 0;
-    if (lds > 48 * 1024 && lds > cfg) {
-        GRHIP_HIP(hipFuncSetAttribute((const void *)pfb_os1_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
-        cfg = lds;
+    if ((a.nout + a.tpf) * 8 > 0xffffffffLL) return -1;         // the stream's buffer descriptor counts bytes in 32 bits
+    switch (tpfp / R) {
+    case 1: return launch_pfb_os1_nt<M, 1>(a, lds, st);
+    case 2: return launch_pfb_os1_nt<M, 2>(a, lds, st);
+    case 3: return launch_pfb_os1_nt<M, 3>(a, lds, st);
+    case 4: return launch_pfb_os1_nt<M, 4>(a, lds, st);
+    default: return launch_pfb_os1_nt<M, 0>(a, lds, st);
     }
-    hipLaunchKernelGGL(pfb_os1_kernel<M>, dim3((unsigned)((a.nout + TT - 1) / TT)), dim3(64 * M), lds, st, a);
-    GRHIP_HIP(hipGetLastError());
-    return GRHIP_OK;
 }
 
 int launch_pfb(const PfbArgs &a, hipStream_t st)
