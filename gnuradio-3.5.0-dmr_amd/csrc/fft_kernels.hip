@@ -469,13 +469,15 @@ typedef const float __attribute__((address_space(4))) *pfb_cfloat_p;
 // per launch and stay in SGPRs, the FIR is straight-line code and the tile's 512 + 8 NT samples per stream are nine
 // 64-lane rounds of range-checked buffer loads (no branches); NT = 0 takes any length with the taps read in the loop.
 template <int M, int NT>
-__global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a, long long ntiles)
+__global__ void __launch_bounds__(64 * M) __attribute__((amdgpu_waves_per_eu(M == 8 ? 6 : 1)))       // (M = 8: 40 KB of LDS -> three per CU)
+pfb_os1_kernel(const PfbArgs a, long long ntiles)
 {
     constexpr int R = 8, TT = 64 * R;                  // output vectors per tile
     constexpr int LOGM = M == 1 ? 0 : M == 2 ? 1 : M == 4 ? 2 : M == 8 ? 3 : 4;
     static_assert((1 << LOGM) == M, "M must be a power of two <= 16");
     typedef float pfb_f32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned int pfb_u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int pfb_u32x4 __attribute__((ext_vector_type(4)));
+    typedef float pfb_f32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tpfp = NT ? R * NT : (a.tpf + R - 1) / R * R;    // taps padded to a multiple of R (zeros)
     const int XS = (TT + tpfp + R) + (TT + tpfp + R) / R + 1;   // slots per stream, padded
@@ -592,10 +594,15 @@ __global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a, long l
         }
         __syncthreads();
 
-        // ---- M-point backward DFT (unnormalised), one output vector per lane
+        // ---- M-point backward DFT (unnormalised), one output vector per lane.  M = 8 (one vector per lane and tile): a
+        // lane's vector is 64 contiguous bytes, so storing it directly would touch 64 separate 64-byte segments per
+        // instruction; the wave's 64 vectors go through its own (by then free) row of LDS instead and leave as
+        // 1 KB-contiguous 16-byte stores.
+        constexpr bool COAL = M == 8;
+        constexpr int PIECES = M / 2 > 0 ? M / 2 : 1;         // 16-byte pieces per vector
         for (int tl = t; tl < TT; tl += 64 * M) {
             const long long tt = t0 + tl;
-            if (tt >= a.nout) continue;
+            if (!COAL && tt >= a.nout) continue;
             float2 v[M];
             // bit-reversed load, then radix-2 decimation-in-time stages
 #pragma unroll
@@ -626,6 +633,27 @@ __global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a, long l
                     }
                 }
             }
+            if (COAL) {
+                __syncthreads();                       // every wave has read its vectors' slots: the rows are free
+                pfb_f32x2 *sc = dst;                   // this wave's row, (M + 1) slots per vector
+#pragma unroll
+                for (int k = 0; k < M; ++k) sc[ln * (M + 1) + k] = (pfb_f32x2){v[k].x, v[k].y};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // the wave's 64 vectors through a descriptor of their own: vectors past nout are out of its range
+                const long long tw0 = t0 + __builtin_amdgcn_readfirstlane(tl - ln);
+                long long left = (a.nout - tw0) * (long long)(8 * M);
+                left = left < 0 ? 0 : (left > 64 * 8 * M ? 64 * 8 * M : left);
+                const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(a.out + tw0 * M, 0, (int)left, 0x00020000);
+#pragma unroll
+                for (int k = 0; k < PIECES; ++k) {
+                    const int idx = 64 * k + ln, vec = idx / PIECES, pc = idx % PIECES;
+                    const pfb_f32x2 p0 = sc[vec * (M + 1) + 2 * pc], p1 = sc[vec * (M + 1) + 2 * pc + 1];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pfb_u32x4, pfb_f32x4{p0.x, p0.y, p1.x, p1.y}), orr, 16 * idx, 0, 0);
+                }
+                continue;
+            }
             float2 *o = a.out + tt * M;
             if (M >= 2) {
                 float4 *o4 = reinterpret_cast<float4 *>(o);
@@ -635,7 +663,7 @@ __global__ void __launch_bounds__(64 * M) pfb_os1_kernel(const PfbArgs a, long l
                 o[0] = v[0];
             }
         }
-        __syncthreads();                               // sl (= xs) belongs to the next tile's samples from here
+        if (M != 8) __syncthreads();                   // sl (= xs) belongs to the next tile's samples from here
     }
 }
 

@@ -118,6 +118,36 @@ def test_pfb_vs_oracle(gpu, po, M, ntaps):
     assert rel_err_max(out, ref) <= 1e-5
 
 
+@pytest.mark.parametrize("M,tpf,nout", [(8, 32, 512 * 2400 + 77), (8, 8, 512 * 1600 + 1), (8, 48, 512 * 800 + 63),
+                                        (4, 32, 512 * 3200 + 5)])
+def test_pfb_persistent_walk(gpu, po, M, tpf, nout):
+    """more tiles than resident workgroups: every workgroup walks several tiles (the next tile's samples in flight), and a
+    ragged last tile whose vectors past nout fall outside the store descriptor; tpf 32 / 8: taps resident in SGPRs,
+    48: taps read in the loop"""
+    import torch
+    rng = np.random.default_rng(M + tpf)
+    taps = rng.uniform(-1, 1, M * tpf).astype(np.float32)
+    o = po.PfbChannelizer(M, taps, 1.0)
+    assert o.taps_per_filter == tpf
+    per = nout + tpf
+    ins = np.zeros((M, per), np.complex64)
+    ins[:, tpf:] = _rc(rng, M * nout).reshape(M, nout)
+    ref, used = o.general_work(nout, [ins[j] for j in range(M)])
+    assert used == nout
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    d_in = torch.from_numpy(ins.view(np.float32).reshape(M * per, 2)).to(dev)
+    d_out = torch.zeros((nout * M + 64, 2), dtype=torch.float32, device=dev)
+    pf = gpu.pfb_channelizer_ccf(M, taps, 1.0)
+    assert pf.general_work_device(nout, d_in, per, d_out, st) == 0      # d_updated from the ctor's set_taps
+    assert pf.general_work_device(nout, d_in, per, d_out, st) == nout
+    st.synchronize()
+    got = d_out.cpu().numpy().reshape(-1).view(np.complex64)
+    assert not got[nout * M:].any()                                     # nothing past the last vector
+    err = np.abs(got[:nout * M].reshape(nout, M) - ref).max(1)
+    assert err.max() <= 1e-5 * np.abs(ref).max(), (int(err.argmax()), float(err.max()))
+
+
 @pytest.mark.parametrize("M,os_rate", [(8, 2.0), (8, 4.0), (6, 1.5), (4, 4.0)])
 def test_pfb_oversampled(gpu, po, M, os_rate):
     rng = np.random.default_rng(int(M * 10 + os_rate))
