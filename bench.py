@@ -186,7 +186,113 @@ def cpu_baseline(wl, x_host, proto, repeats=2):
                             "sample": "%d streams x %d samples" % (ncpu, len(sub))}
     except Exception as e:  # pragma: no cover
         res["all_cores"] = {"error": str(e)}
+    try:
+        res["chain"] = cpu_chain_baseline(wl, x_host, proto, lib)
+    except Exception as e:  # pragma: no cover
+        res["chain"] = {"error": str(e)}
     return res
+
+
+def cpu_chain_baseline(wl, x_host, proto, lib):
+    """SURVEY 8(d) CPU legs for the full chain (config 4): xlating FIR + demodulator -> M&M clock recovery -> slicer ->
+    access-code correlator on this box's host cores.  (i) one thread, stage after stage; (ii) one thread per block over
+    64 k-item chunks, the shape of the reference's thread-per-block scheduler (gr_scheduler_tpb.cc:70-77: the slowest
+    block sets the rate); (iii) one independent capture per host thread.  Stages are the oracle's C (the reference's
+    SSE dot product where oracle/_ref is built, leg (i) and (iii) only -- the chunked leg needs the stateful port)."""
+    import queue
+    import threading
+    po = grhip_loader.import_oracle()
+    c, c4 = wl.CFG2, wl.CFG4
+    code = wl.access_code_string()
+    x = x_host[: min(len(x_host), 2_000_000)]
+
+    def serial(xs, which):
+        d = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], xs, lib=which)
+        sym, _ = po.chain_mm(c4["omega"], c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], d)
+        return po.CorrelateAccessCode(code, c4["threshold"]).work(po.binary_slicer_fb(sym))
+
+    t0 = time.perf_counter()
+    flags = serial(x, lib)
+    t_serial = time.perf_counter() - t0
+    out = {"unit": "Msamples/s of complex input",
+           "serial_1_thread": {"value": len(x) / t_serial / 1e6, "cores": 1, "kind": "reference" if lib == "ref" else "port",
+                               "sync_flags": int((flags >> 1).sum()), "sample": "%d samples" % len(x)}}
+
+    # (ii) thread per block
+    D, nt = c["decim"], len(proto)
+    CH = 65536                                   # output items of the FIR per chunk
+    xin = wl.with_history(x, nt - 1)
+    nout = len(x) // D
+    q1, q2, q3, q4 = (queue.Queue(maxsize=4) for _ in range(4))
+
+    def t_fir():
+        f = po.Xlating(D, proto, c["center_freq"], c["fs"])
+        for pos in range(0, nout, CH):
+            m = min(CH, nout - pos)
+            q1.put(f.work(xin[pos * D: pos * D + (m - 1) * D + nt], m))
+        q1.put(None)
+
+    def t_demod():
+        last = np.zeros(1, np.complex64)
+        while True:
+            y = q1.get()
+            if y is None:
+                break
+            yh = np.concatenate([last, y])
+            q2.put(po.quad_demod_cf(c["demod_gain"], yh, len(y)))
+            last = y[-1:]
+        q2.put(None)
+
+    def t_mm():
+        mm = po.ClockRecoveryMM(c4["omega"], c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"])
+        left = np.zeros(0, np.float32)
+        while True:
+            d = q2.get()
+            if d is None:
+                break
+            buf = np.concatenate([left, d])
+            o_, used = mm.general_work(len(buf), buf)
+            left = buf[used:]
+            q3.put(o_)
+        q3.put(None)
+
+    def t_slice():
+        while True:
+            s_ = q3.get()
+            if s_ is None:
+                break
+            q4.put(po.binary_slicer_fb(s_))
+        q4.put(None)
+
+    nflags = [0]
+
+    def t_corr():
+        corr = po.CorrelateAccessCode(code, c4["threshold"])
+        while True:
+            b = q4.get()
+            if b is None:
+                break
+            nflags[0] += int((corr.work(b) >> 1).sum())
+
+    ths = [threading.Thread(target=f) for f in (t_fir, t_demod, t_mm, t_slice, t_corr)]
+    t0 = time.perf_counter()
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    t_tpb = time.perf_counter() - t0
+    out["thread_per_block"] = {"value": len(x) / t_tpb / 1e6, "cores": len(ths), "kind": "port",
+                               "sync_flags": nflags[0], "sample": "%d samples in %d-item chunks, 5 block threads" % (len(x), CH)}
+
+    # (iii) one capture per host thread
+    ncpu = os.cpu_count() or 1
+    sub = x[: 1_000_000]
+    ths = [threading.Thread(target=serial, args=(sub, lib)) for _ in range(ncpu)]
+    t0 = time.perf_counter()
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    out["all_cores"] = {"value": ncpu * len(sub) / dt / 1e6, "cores": ncpu, "kind": "reference" if lib == "ref" else "port",
+                        "sample": "%d captures x %d samples" % (ncpu, len(sub))}
+    return out
 
 
 def measured_traffic(kernel, captures, samples, launches_per_step):

@@ -47,3 +47,20 @@ def test_failing_rank_fails_the_run():
     if torch.cuda.is_available():
         return
     assert r.returncode != 0
+
+
+def test_cpu_chain_baseline_legs_agree():
+    """bench.py's cpu_baseline "chain" legs (SURVEY 8d i-iii): the stage-after-stage run and the thread-per-block pipeline over
+    64 k-item chunks are the same computation -- same number of access-code flags -- and every leg reports a rate"""
+    import importlib.util
+    import grhip_loader
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    wl = grhip_loader.import_grhip().workload
+    po = grhip_loader.import_oracle()
+    x = wl.fsk4_capture(600_000)
+    r = b.cpu_chain_baseline(wl, x, wl.cfg2_proto_taps(), "ref" if po.have_ref() else "oracle")
+    assert r["serial_1_thread"]["sync_flags"] == r["thread_per_block"]["sync_flags"] >= 4
+    for leg in ("serial_1_thread", "thread_per_block", "all_cores"):
+        assert r[leg]["value"] > 0 and r[leg]["cores"] >= 1
