@@ -64,3 +64,34 @@ def test_cpu_chain_baseline_legs_agree():
     assert r["serial_1_thread"]["sync_flags"] == r["thread_per_block"]["sync_flags"] >= 4
     for leg in ("serial_1_thread", "thread_per_block", "all_cores"):
         assert r[leg]["value"] > 0 and r[leg]["cores"] >= 1
+
+
+def test_bench_generator_is_the_parity_workload():
+    """bench.py synthesises its captures with torch on the device; the parity tests use workload.fsk4_capture (numpy).
+    Same waveform: the two are phase-coherent sample by sample (noise apart, which comes from different generators at the
+    same level), so the benchmark runs on the signal the parity tests check."""
+    import importlib.util
+    import numpy as np
+    import torch
+    import grhip_loader
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    wl = grhip_loader.import_grhip().workload
+    n = 400_000
+    for sid in (0, 5):
+        xb = b.synth_captures(torch, wl, 1, n, sid, torch.device("cpu"))[0].numpy()
+        xb = xb[:, 0] + 1j * xb[:, 1]
+        xw = wl.fsk4_capture(n, stream_id=sid)
+        c = wl.CFG2
+        sps = int(round(c["fs"] / c["sym_rate"]))
+        n0 = sps / (10.0 ** (c["esn0_db"] / 10.0))            # noise variance per complex sample, unit-power signal
+        # E[x_b conj(x_w)] = |s|^2 = 1 when the noiseless parts agree in phase at every sample
+        coh = np.mean(xb * np.conj(xw))
+        tol = 6 * np.sqrt((2 * n0 + n0 * n0) / n)
+        assert abs(coh.real - 1.0) < tol + 1e-3 and abs(coh.imag) < tol + 1e-3, coh
+        # same noise level: E|x|^2 = 1 + n0 for both
+        for x in (xb, xw):
+            assert abs(np.mean(np.abs(x) ** 2) - (1 + n0)) < 0.02 * (1 + n0)
+        # and the difference of the two is noise only: E|x_b - x_w|^2 = 2 n0
+        assert abs(np.mean(np.abs(xb - xw) ** 2) - 2 * n0) < 0.03 * 2 * n0 + 1e-3
