@@ -4,6 +4,7 @@
 #include <map>
 
 #include "grhip_internal.h"
+#include <cstring>
 #include "tables.inc"
 
 namespace grhip {
@@ -60,9 +61,84 @@ int HandleBase::bind() const
     return GRHIP_OK;
 }
 
+int HandleBase::pin_init(PinRing &r)
+{
+    if (r.buf[0]) return GRHIP_OK;
+    for (int k = 0; k < 2; ++k) {
+        GRHIP_HIP(hipHostMalloc(&r.buf[k], PIN_SLOT, hipHostMallocDefault));
+        GRHIP_HIP(hipEventCreateWithFlags(&r.ev[k], hipEventDisableTiming));
+        r.busy[k] = false;
+    }
+    r.next = 0;
+    return GRHIP_OK;
+}
+
+void HandleBase::pin_release(PinRing &r)
+{
+    for (int k = 0; k < 2; ++k) {
+        if (r.ev[k]) { if (r.busy[k]) (void)hipEventSynchronize(r.ev[k]); (void)hipEventDestroy(r.ev[k]); }
+        if (r.buf[k]) (void)hipHostFree(r.buf[k]);
+        r.buf[k] = nullptr; r.ev[k] = nullptr; r.busy[k] = false;
+    }
+}
+
+int HandleBase::h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return GRHIP_OK;
+    if (bytes > PIN_MAX) {
+        GRHIP_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+        return GRHIP_OK;
+    }
+    int rc = pin_init(pin_up);
+    if (rc) return rc;
+    PinRing &r = pin_up;
+    for (size_t off = 0; off < bytes; off += PIN_SLOT) {
+        const size_t n = bytes - off < PIN_SLOT ? bytes - off : PIN_SLOT;
+        const int k = r.next;
+        if (r.busy[k]) { GRHIP_HIP(hipEventSynchronize(r.ev[k])); r.busy[k] = false; }    // its last DMA has read it
+        memcpy(r.buf[k], (const char *)src_host + off, n);
+        GRHIP_HIP(hipMemcpyAsync((char *)dst_dev + off, r.buf[k], n, hipMemcpyHostToDevice, st));
+        GRHIP_HIP(hipEventRecord(r.ev[k], st));
+        r.busy[k] = true;
+        r.next = k ^ 1;
+    }
+    return GRHIP_OK;
+}
+
+int HandleBase::d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return GRHIP_OK;
+    if (bytes > PIN_MAX) {
+        GRHIP_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        return GRHIP_OK;
+    }
+    int rc = pin_init(pin_down);
+    if (rc) return rc;
+    PinRing &r = pin_down;
+    size_t p_off = 0, p_n = 0;
+    int p_k = -1;
+    for (size_t off = 0; off < bytes; off += PIN_SLOT) {
+        const size_t n = bytes - off < PIN_SLOT ? bytes - off : PIN_SLOT;
+        const int k = r.next;       // free: its previous content was copied out before this slot came round again
+        GRHIP_HIP(hipMemcpyAsync(r.buf[k], (const char *)src_dev + off, n, hipMemcpyDeviceToHost, st));
+        GRHIP_HIP(hipEventRecord(r.ev[k], st));
+        if (p_k >= 0) {
+            GRHIP_HIP(hipEventSynchronize(r.ev[p_k]));
+            memcpy((char *)dst_host + p_off, r.buf[p_k], p_n);
+        }
+        p_off = off; p_n = n; p_k = k;
+        r.next = k ^ 1;
+    }
+    GRHIP_HIP(hipEventSynchronize(r.ev[p_k]));
+    memcpy((char *)dst_host + p_off, r.buf[p_k], p_n);
+    return GRHIP_OK;
+}
+
 void HandleBase::destroy_base()
 {
     (void)hipSetDevice(device);
+    pin_release(pin_up);
+    pin_release(pin_down);
     stage_in.release();
     stage_out.release();
     if (own_stream) (void)hipStreamDestroy(own_stream);

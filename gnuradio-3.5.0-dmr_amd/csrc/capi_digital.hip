@@ -151,7 +151,7 @@ int grhip_clock_recovery_mm_ff_general_work(grhip_clock_recovery_mm_ff *h, int n
     if ((rc = h->stage_in.reserve((size_t)(ninput_items > 0 ? ninput_items : 1) * 4))) return rc;
     if ((rc = h->stage_out.reserve((size_t)(noutput_items > 0 ? noutput_items : 1) * 4))) return rc;
     hipStream_t st = h->own_stream;
-    if (ninput_items) GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, (size_t)ninput_items * 4, hipMemcpyHostToDevice, st));
+    if (ninput_items) GRHIP_H2D(h, h->stage_in.p, in, (size_t)ninput_items * 4, st);
     rc = launch_mm(h->d_state.as<MMState>(), 1, noutput_items, ninput_items, h->stage_in.as<float>(), 0,
                    h->stage_out.as<float>(), 0, h->d_counts.as<int>(), h->tabs->mmse_rev, st);
     if (rc) return rc;
@@ -236,10 +236,10 @@ int grhip_binary_slicer_fb_work(grhip_binary_slicer_fb *h, int noutput_items, co
     if ((rc = h->stage_in.reserve(n * 4))) return rc;
     if ((rc = h->stage_out.reserve(n))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n * 4, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, n * 4, st);
     if ((rc = launch_binary_slicer(h->stage_in.as<float>(), h->stage_out.as<unsigned char>(), (long long)n, st)))
         return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, n, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, n, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }
@@ -293,11 +293,11 @@ int grhip_pager_slicer_fb_work(grhip_pager_slicer_fb *h, int noutput_items, cons
     if ((rc = h->stage_in.reserve(n * 4))) return rc;
     if ((rc = h->stage_out.reserve(n))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n * 4, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, n * 4, st);
     if ((rc = launch_pager_slicer(h->d_avg.as<float>(), 1, h->alpha, h->beta, h->stage_in.as<float>(), 0,
                                   h->stage_out.as<unsigned char>(), 0, (long long)n, st)))
         return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, n, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, n, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }
@@ -358,10 +358,10 @@ int grhip_unpack_k_bits_bb_work(grhip_unpack_k_bits_bb *h, int noutput_items, co
     if ((rc = h->stage_in.reserve(ni))) return rc;
     if ((rc = h->stage_out.reserve(n))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, ni, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, ni, st);
     if ((rc = launch_unpack_k_bits(h->k, h->stage_in.as<unsigned char>(), h->stage_out.as<unsigned char>(), (long long)n, st)))
         return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, n, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, n, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }
@@ -414,17 +414,17 @@ int grhip_stream_adapter_work(grhip_stream_adapter *h, int n, void *single, void
     hipStream_t st = h->own_stream;
     // stage_in holds the single stream, stage_out the nstreams streams back to back
     if (h->split) {
-        GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, single, tot, hipMemcpyHostToDevice, st));
+        GRHIP_H2D(h, h->stage_in.p, single, tot, st);
     } else {
         for (size_t j = 0; j < h->nstreams; ++j)
-            GRHIP_HIP(hipMemcpyAsync((char *)h->stage_out.p + j * per, streams[j], per, hipMemcpyHostToDevice, st));
+            GRHIP_H2D(h, (char *)h->stage_out.p + j * per, streams[j], per, st);
     }
     if ((rc = launch_streams(h->split, h->stage_in.p, h->stage_out.p, n, (int)h->nstreams, h->item_size, n, st))) return rc;
     if (h->split) {
         for (size_t j = 0; j < h->nstreams; ++j)
-            GRHIP_HIP(hipMemcpyAsync(streams[j], (char *)h->stage_out.p + j * per, per, hipMemcpyDeviceToHost, st));
+            GRHIP_D2H(h, streams[j], (char *)h->stage_out.p + j * per, per, st);
     } else {
-        GRHIP_HIP(hipMemcpyAsync(single, h->stage_in.p, tot, hipMemcpyDeviceToHost, st));
+        GRHIP_D2H(h, single, h->stage_in.p, tot, st);
     }
     GRHIP_HIP(hipStreamSynchronize(st));
     return n;
@@ -501,11 +501,11 @@ int grhip_correlate_access_code_bb_work(grhip_correlate_access_code_bb *h, int n
     if ((rc = h->stage_in.reserve(n + 8))) return rc;
     if ((rc = h->stage_out.reserve(n + 8))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, n, st);
     rc = grhip_correlate_access_code_bb_work_device(h, noutput_items, h->stage_in.as<unsigned char>(),
                                                     h->stage_out.as<unsigned char>(), st);
     if (rc < 0) return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, n, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, n, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }

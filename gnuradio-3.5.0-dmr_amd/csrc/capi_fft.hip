@@ -130,10 +130,10 @@ int grhip_fft_vcc_work(grhip_fft_vcc *h, int noutput_items, const void *in, void
     if ((rc = h->stage_in.reserve(bytes))) return rc;
     if ((rc = h->stage_out.reserve(bytes))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, bytes, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, bytes, st);
     rc = grhip_fft_vcc_work_device(h, noutput_items, h->stage_in.p, h->stage_out.p, st);
     if (rc < 0) return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, bytes, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, bytes, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }
@@ -278,7 +278,7 @@ int grhip_pfb_channelizer_ccf_general_work(grhip_pfb_channelizer_ccf *h, int nou
     a.out = h->stage_out.as<float2>(); a.nout = nvalid;
     if ((rc = launch_pfb(a, st))) return rc;
     if (nvalid > 0)
-        GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, (size_t)nvalid * h->M * 8, hipMemcpyDeviceToHost, st));
+        GRHIP_D2H(h, out, h->stage_out.p, (size_t)nvalid * h->M * 8, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }

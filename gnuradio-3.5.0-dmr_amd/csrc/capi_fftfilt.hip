@@ -174,10 +174,10 @@ int grhip_fft_filter_ccc_work(grhip_fft_filter_ccc *h, int noutput_items, const 
     const size_t nin = (size_t)noutput_items * h->decim;
     if ((rc = h->stage_in.reserve(nin * 8))) return rc;
     if ((rc = h->stage_out.reserve((size_t)noutput_items * 8))) return rc;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, nin * 8, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, nin * 8, st);
     rc = grhip_fft_filter_ccc_work_device(h, noutput_items, h->stage_in.p, h->stage_out.p, st);
     if (rc < 0) return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, (size_t)noutput_items * 8, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, (size_t)noutput_items * 8, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return rc;
 }

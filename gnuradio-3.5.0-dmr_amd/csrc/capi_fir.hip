@@ -664,9 +664,9 @@ int grhip_fir_filter_work(grhip_fir_filter *h, int noutput_items, const void *in
     if ((rc = h->stage_in.reserve(n_in * h->in_item() + 16))) return rc;
     if ((rc = h->stage_out.reserve((size_t)n * h->out_item()))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n_in * h->in_item(), hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, n_in * h->in_item(), st);
     if ((rc = h->run(h->stage_in.p, h->stage_out.p, n, h->decim, st))) return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, (size_t)n * h->out_item(), hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, (size_t)n * h->out_item(), st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }
@@ -684,9 +684,9 @@ int grhip_fir_filterNdec(grhip_fir_filter *h, void *output, const void *input, u
     if ((rc = h->stage_in.reserve(n_in * h->in_item() + 16))) return rc;
     if ((rc = h->stage_out.reserve((size_t)n * h->out_item()))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, input, n_in * h->in_item(), hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, input, n_in * h->in_item(), st);
     if ((rc = h->run(h->stage_in.p, h->stage_out.p, (long long)n, (int)decimate, st))) return rc;
-    GRHIP_HIP(hipMemcpyAsync(output, h->stage_out.p, (size_t)n * h->out_item(), hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, output, h->stage_out.p, (size_t)n * h->out_item(), st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return GRHIP_OK;
 }
@@ -844,10 +844,10 @@ int grhip_fir_filter_with_buffer_filterNdec(grhip_fir_filter_with_buffer *h, voi
     if ((rc = h->stage_in.reserve(nin * it + 16))) return rc;
     if ((rc = h->stage_out.reserve((size_t)n * it))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, input, nin * it, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, input, nin * it, st);
     rc = grhip_fir_filter_with_buffer_filterNdec_device(h, h->stage_out.p, h->stage_in.p, n, decimate, st);
     if (rc) return rc;
-    GRHIP_HIP(hipMemcpyAsync(output, h->stage_out.p, (size_t)n * it, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, output, h->stage_out.p, (size_t)n * it, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return GRHIP_OK;
 }
@@ -1014,11 +1014,11 @@ int grhip_freq_xlating_fir_filter_ccc_work(grhip_freq_xlating_fir_filter_ccc *h,
     if ((rc = h->stage_in.reserve(n_in * 8 + 16))) return rc;
     if ((rc = h->stage_out.reserve((size_t)n * 8))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n_in * 8, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, n_in * 8, st);
     rc = h->core.run(h->mode, h->stage_in.as<float2>(), (long long)n_in, n, h->stage_out.as<float2>(), nullptr,
                      0.f, nullptr, nullptr, nullptr, st);
     if (rc) return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, (size_t)n * 8, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }
@@ -1068,11 +1068,11 @@ int grhip_quadrature_demod_cf_work(grhip_quadrature_demod_cf *h, int noutput_ite
     if ((rc = h->stage_in.reserve((n + 1) * 8))) return rc;
     if ((rc = h->stage_out.reserve(n * 4))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, (n + 1) * 8, st);
     if ((rc = launch_quad_demod(h->stage_in.as<float2>(), h->stage_out.as<float>(), (long long)n, h->gain,
                                 h->tabs->atan_tab, st)))
         return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, n * 4, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, n * 4, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }
@@ -1202,10 +1202,10 @@ int grhip_xlating_demod_work(grhip_xlating_demod *h, int noutput_items, const vo
     if ((rc = h->stage_in.reserve(n_in * 8 + 16))) return rc;
     if ((rc = h->stage_out.reserve((size_t)n * 4))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, n_in * 8, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, n_in * 8, st);
     rc = grhip_xlating_demod_work_device(h, noutput_items, h->stage_in.p, h->stage_out.p, st);
     if (rc < 0) return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, (size_t)n * 4, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }

@@ -871,7 +871,7 @@ int grhip_framer_sink_1_work(grhip_framer_sink_1 *h, int noutput_items, const un
     if (rc) return rc;
     if ((rc = h->stage_in.reserve((size_t)noutput_items))) return rc;
     hipStream_t st = h->own_stream;
-    GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, (size_t)noutput_items, hipMemcpyHostToDevice, st));
+    GRHIP_H2D(h, h->stage_in.p, in, (size_t)noutput_items, st);
     rc = grhip_framer_sink_1_work_device(h, noutput_items, h->stage_in.as<unsigned char>(), st);
     if (rc < 0) return rc;
     GRHIP_HIP(hipStreamSynchronize(st));

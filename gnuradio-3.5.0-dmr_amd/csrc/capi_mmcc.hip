@@ -287,11 +287,11 @@ int grhip_clock_recovery_mm_cc_general_work(grhip_clock_recovery_mm_cc *h, int n
     hipStream_t st = h->own_stream;
     if ((rc = h->stage_in.reserve((size_t)ninput_items * 8 + 8))) return rc;
     if ((rc = h->stage_out.reserve((size_t)noutput_items * 12 + 16))) return rc;
-    if (ninput_items) GRHIP_HIP(hipMemcpyAsync(h->stage_in.p, in, (size_t)ninput_items * 8, hipMemcpyHostToDevice, st));
+    if (ninput_items) GRHIP_H2D(h, h->stage_in.p, in, (size_t)ninput_items * 8, st);
     float *d_err = err ? (float *)((char *)h->stage_out.p + (size_t)noutput_items * 8) : nullptr;
     int n = mmcc_run(h, noutput_items, ninput_items, h->stage_in.p, h->stage_out.p, d_err, consumed, st);
     if (n <= 0) return n;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, (size_t)n * 8, st);
     if (err) GRHIP_HIP(hipMemcpyAsync(err, d_err, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     GRHIP_HIP(hipStreamSynchronize(st));
     return n;

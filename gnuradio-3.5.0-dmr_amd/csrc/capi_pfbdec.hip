@@ -226,10 +226,10 @@ int grhip_pfb_decimator_ccf_work(grhip_pfb_decimator_ccf *h, int noutput_items, 
     if ((rc = h->stage_out.reserve((size_t)noutput_items * 8))) return rc;
     hipStream_t st = h->own_stream;
     for (unsigned j = 0; j < h->M; ++j)
-        GRHIP_HIP(hipMemcpyAsync(h->stage_in.as<float2>() + (size_t)j * per, ins[j], per * 8, hipMemcpyHostToDevice, st));
+        GRHIP_H2D(h, h->stage_in.as<float2>() + (size_t)j * per, ins[j], per * 8, st);
     rc = grhip_pfb_decimator_ccf_work_device(h, noutput_items, h->stage_in.p, per, h->stage_out.p, st);
     if (rc < 0) return rc;
-    GRHIP_HIP(hipMemcpyAsync(out, h->stage_out.p, (size_t)noutput_items * 8, hipMemcpyDeviceToHost, st));
+    GRHIP_D2H(h, out, h->stage_out.p, (size_t)noutput_items * 8, st);
     GRHIP_HIP(hipStreamSynchronize(st));
     return noutput_items;
 }

@@ -65,11 +65,29 @@ struct SchedBuf {
 };
 
 // ---- base of every block handle -------------------------------------------
+#define GRHIP_H2D(h, dst, src, bytes, st) do { int rc__ = (h)->h2d((dst), (src), (bytes), (st)); if (rc__) return rc__; } while (0)
+#define GRHIP_D2H(h, dst, src, bytes, st) do { int rc__ = (h)->d2h((dst), (src), (bytes), (st)); if (rc__) return rc__; } while (0)
+
 struct HandleBase {
     int device = 0;
     hipStream_t own_stream = nullptr;
     std::mutex setter_mutex;   // setters vs. the work thread
     DevBuf stage_in, stage_out;
+    // Pinned staging of the host-buffer entry points (SURVEY 8b "Ownership": the handle owns it, the caller owns its I/O
+    // buffers).  Scheduler-sized transfers (<= PIN_MAX) go caller buffer -> pinned slot -> DMA and back: no page pinning or
+    // runtime staging per call; two slots per direction, so a call split in chunks copies one while the other is in flight.
+    // Larger transfers are left to the runtime: measured (tools/bench_small_calls.py) its own staging wins from a few hundred KB.
+    static constexpr size_t PIN_SLOT = 32 * 1024, PIN_MAX = 64 * 1024;
+    struct PinRing {
+        void *buf[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool busy[2] = {false, false};
+        int next = 0;
+    } pin_up, pin_down;
+    int pin_init(PinRing &r);
+    void pin_release(PinRing &r);
+    int h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t st);
+    int d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t st);     // complete on return (<= PIN_MAX) or queued
 
     int init_device(int dev);
     void destroy_base();
