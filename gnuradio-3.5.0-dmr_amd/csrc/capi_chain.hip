@@ -33,7 +33,13 @@ struct grhip_dmr_chain : HandleBase {
     int mode = GRHIP_MODE_FAST;
     // FAST modes: the capture is processed in PIPE_CHUNKS time slices; the clock recovery of slice c (second
     // stream) runs beside the FIR of slice c+1
-    static constexpr int PIPE_CHUNKS = 8;
+#ifndef GRHIP_PIPE_CHUNKS
+#define GRHIP_PIPE_CHUNKS 16
+#endif
+#ifndef GRHIP_CHAIN_WGCAP
+#define GRHIP_CHAIN_WGCAP 1
+#endif
+    static constexpr int PIPE_CHUNKS = GRHIP_PIPE_CHUNKS;
     // 4FSK tail (grhip_dmr_chain_set_four_level): pager_slicer_fb -> unpack_k_bits(2) in front of the correlator
     bool four_level = false;
     float pager_alpha = 0.f;
@@ -157,7 +163,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         GRHIP_HIP(hipEventRecord(h->ev_begin, st));
         GRHIP_HIP(hipStreamWaitEvent(h->st2, h->ev_begin, 0));
         st_mm = NC > 1 ? h->st2 : st;
-        h->core.mf_wg_cap = NC > 1 ? 1 : 0;
+        h->core.mf_wg_cap = NC > 1 ? GRHIP_CHAIN_WGCAP : 0;
         for (int c = 0; c < NC; ++c) {
             const long long o0 = (long long)c * Lc;
             if (o0 >= n_out) break;

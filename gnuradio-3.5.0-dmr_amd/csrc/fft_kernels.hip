@@ -741,39 +741,49 @@ int launch_pfb(const PfbArgs &a, hipStream_t st)
 // The reference block is overlap-ADD with its own transform size; both are the same
 // convolution to within transform rounding (its FFTs are FFTW: unpinned anyway).
 // ===========================================================================
-template <bool FWD>
-__device__ __forceinline__ void fft4096_mid_passes(float2 (&v)[16], float2 *S, const float2 *__restrict__ twiddle, int t)
+// a * conj(b) in two packed instructions
+__device__ __forceinline__ f32x2_t cmul_conj_pk(f32x2_t a, f32x2_t b)
 {
-    auto pad = [](int i) { return i + (i >> 4); };
-    // pass 1 has been done by the caller's dft16; exchange, pass 2, exchange, pass 3
+    f32x2_t t, r;
+    // t = (a.y * b.y, a.y * b.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    // r = (fma(a.x, b.x, t.x), fma(a.x, -b.y, t.y)) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+
+// exchange + pass 2 + exchange + pass 3 of a 4096-point transform whose pass 1 the caller has done (dft16 on v).
+// w3 = the last pass's twiddles of the FORWARD transform, W_N^{t q}, resident in registers; W2 = the middle pass's,
+// W_N^{16 k q} at [k * 17 + q] in LDS; the backward transform multiplies by their conjugates.
+template <bool FWD>
+__device__ __forceinline__ void fft4096_mid_passes(f32x2_t (&v)[16], f32x2_t *S, const f32x2_t *W2, const f32x2_t (&w3)[16], int t)
+{
 #pragma unroll
-    for (int m = 0; m < 16; ++m) S[pad(16 * t + m)] = v[m];
+    for (int m = 0; m < 16; ++m) S[17 * t + m] = v[m];
     __syncthreads();
     {
         const int k = t & 15;
-        float2 w[16];
 #pragma unroll
-        for (int q = 1; q < 16; ++q) w[q] = tw<FWD>(twiddle, 16 * k * q);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = S[pad(t + 256 * q)];
+        for (int q = 0; q < 16; ++q) v[q] = S[t + (t >> 4) + 272 * q];
         __syncthreads();
 #pragma unroll
-        for (int q = 1; q < 16; ++q) v[q] = cmul2(v[q], w[q]);
+        for (int q0 = 0; q0 < 16; q0 += 2) {
+#pragma unroll
+            for (int q = q0 ? q0 : 1; q < q0 + 2; ++q) v[q] = FWD ? cmul_pk(v[q], W2[k * 17 + q]) : cmul_conj_pk(v[q], W2[k * 17 + q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         dft16<FWD>(v);
         const int j = (t - k) * 16 + k;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) S[pad(j + 16 * m)] = v[m];
+        for (int m = 0; m < 16; ++m) S[j + (j >> 4) + 17 * m] = v[m];
         __syncthreads();
     }
     {
-        float2 w[16];
 #pragma unroll
-        for (int q = 1; q < 16; ++q) w[q] = tw<FWD>(twiddle, t * q);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = S[pad(t + 256 * q)];
+        for (int q = 0; q < 16; ++q) v[q] = S[t + (t >> 4) + 272 * q];
         __syncthreads();                    // S is reused by the next transform
 #pragma unroll
-        for (int q = 1; q < 16; ++q) v[q] = cmul2(v[q], w[q]);
+        for (int q = 1; q < 16; ++q) v[q] = FWD ? cmul_pk(v[q], w3[q]) : cmul_conj_pk(v[q], w3[q]);
         dft16<FWD>(v);
     }
 }
@@ -783,103 +793,171 @@ __device__ __forceinline__ void fft4096_mid_passes(float2 (&v)[16], float2 *S, c
 // FOLD = log2(decimation) for decimations 2, 4, 8, 16 (0: any decimation, full-size inverse).  Keeping every
 // D-th output of the block, starting at its first valid one (offset ntaps-1: that shift is folded into H on the
 // host), is the (4096/D)-point inverse transform of the spectrum folded D times: the inverse costs 1/D-th.
+// Persistent workgroups (three per CU) walk the blocks as fft4096_kernel walks its vectors: twiddles resident, the next
+// block's points requested under this block's backward transform.
 template <bool REAL, int FOLD>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, 3)
 fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__restrict__ hist_v, int ntaps,
                    const float2 *__restrict__ twiddle, const float2 *__restrict__ H, void *__restrict__ out_v,
-                   long long nout, int decim, int L)
+                   long long nout, int decim, int L, long long nblk)
 {
     constexpr int N = 4096;
-    __shared__ float2 S[N + N / 16];
+    __shared__ f32x2_t S[N + N / 16];
+    __shared__ f32x2_t W2[16 * 17];
+    typedef unsigned int ols_u32x2 __attribute__((ext_vector_type(2)));
     const int t = threadIdx.x;
-    const long long b = blockIdx.x;
-    const long long base = b * L - (ntaps - 1);          // stream index of block position 0
-    float2 v[16];
+    f32x2_t w3[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const long long i = base + t + 256 * q;
-        float2 x = make_float2(0.f, 0.f);
-        if (REAL) {
-            const float *in = (const float *)in_v, *hist = (const float *)hist_v;
-            if (i >= 0) { if (i < nin) x.x = in[i]; }
-            else x.x = hist[i + (ntaps - 1)];
+    for (int q = 1; q < 16; ++q) { const float2 w = twiddle[t * q]; w3[q] = f32x2_t{w.x, w.y}; }
+    {
+        const float2 w = twiddle[16 * (t >> 4) * (t & 15)];
+        W2[(t >> 4) * 17 + (t & 15)] = f32x2_t{w.x, w.y};          // visible after the first barrier of the loop
+    }
+    // the stream through a raw buffer descriptor: items past nin (and, as unsigned offsets, before 0) read as zero
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(in_v), 0, (int)(nin * (REAL ? 4 : 8)), 0x00020000);
+    f32x2_t pre[16];
+    auto request = [&](long long b) __attribute__((always_inline)) {
+        const long long base = b * L - (ntaps - 1);          // stream index of block position 0
+        // Offsets: the hardware's range check looks at vector offset + immediate, not at the scalar offset, and a NEGATIVE
+        // vector offset whose immediate brings it back into range does not come out as the in-range load it is (measured:
+        // the stream's first sample read as zero).  So the whole offset goes into the VGPR, and in the blocks that start
+        // before the stream (b L < ntaps - 1: one or two per call) the positions before it get an explicit out-of-range
+        // offset through a select, which also keeps the compiler from splitting the sum into register + immediate.
+        const int vo = (int)((base + t) * (REAL ? 4 : 8));
+        if (base < 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int off = (base + t + 256 * q >= 0) ? vo + 256 * (REAL ? 4 : 8) * q : 0x7ffffff0;
+                if (REAL) pre[q] = f32x2_t{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0)), 0.f};
+                else pre[q] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
+            }
         } else {
-            const float2 *in = (const float2 *)in_v, *hist = (const float2 *)hist_v;
-            if (i >= 0) { if (i < nin) x = in[i]; }
-            else x = hist[i + (ntaps - 1)];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (REAL) pre[q] = f32x2_t{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo + 256 * 4 * q, 0, 0)), 0.f};
+                else pre[q] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(xr, vo + 256 * 8 * q, 0, 0));
+            }
         }
-        v[q] = x;
-    }
-    dft16<true>(v);
-    fft4096_mid_passes<true>(v, S, twiddle, t);          // v[m] = X[t + 256 m]
+    };
+    long long b = blockIdx.x;
+    if (b < nblk) request(b);
+    for (; b < nblk; b += gridDim.x) {
+        f32x2_t v[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = cmul2(v[m], H[t + 256 * m]);
-    if (FOLD > 0) {
-        constexpr int DD = 1 << FOLD, NP = N >> FOLD, MP = 16 >> FOLD;     // decimation, inverse size, bins per lane
-        // bin t + 256 m folds onto t + 256 (m mod MP): inside the lane
-        float2 *A = S, *B = S + NP;
+        for (int q = 0; q < 16; ++q) v[q] = pre[q];
+        if (b * L < ntaps - 1) {
+            // positions before the call come from the history (block 0, and the next ones too while b L < ntaps - 1):
+            // block position p is history item b L + p, and every position past the history's end is out of its
+            // descriptor's range (zero) -- as the stream's loads returned zero for the positions before the stream: the
+            // sum of the two is the block, without a branch per lane
+            const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(hist_v), 0, (ntaps - 1) * (REAL ? 4 : 8), 0x00020000);
+            const int hb = ((int)(b * L) + t) * (REAL ? 4 : 8);
 #pragma unroll
-        for (int mp = 0; mp < MP; ++mp) {
-            float2 f = v[mp];
-#pragma unroll
-            for (int a = 1; a < DD; ++a) f = c_add(f, v[mp + a * MP]);
-            A[t + 256 * mp] = f;
+            for (int q = 0; q < 16; ++q) {
+                if (REAL) v[q].x += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr, hb + 256 * 4 * q, 0, 0));
+                else v[q] = v[q] + __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(hr, hb + 256 * 8 * q, 0, 0));
+            }
         }
-        __syncthreads();
-        // (4096/D)-point backward transform, radix-4 Stockham passes (+ one radix-2) between the halves of S
-        float2 *src = A, *dst = B;
-        int p = 1;
-        constexpr int T4 = NP >> 2;
-        while (p * 4 <= NP) {
-            const int tstep = (NP / (4 * p)) << FOLD;              // step in the 4096-entry twiddle table
-            for (int i = t; i < T4; i += 256) {
-                const int k = i & (p - 1);
-                const int j = ((i - k) << 2) + k;
-                const int m = k * tstep;
-                float2 u0 = src[i], u1 = src[i + T4], u2 = src[i + 2 * T4], u3 = src[i + 3 * T4];
-                if (p > 1) {
-                    u1 = cmul2(u1, tw<false>(twiddle, m));
-                    u2 = cmul2(u2, tw<false>(twiddle, 2 * m));
-                    u3 = cmul2(u3, tw<false>(twiddle, 3 * m));
+        // the lane's sixteen bins of H travel (from L2) in the registers the block's points have just left, under the
+        // forward transform; the next block's points take the same registers under the backward one
+        f32x2_t Hr[16];
+        const __amdgpu_buffer_rsrc_t Hd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(H), 0, N * 8, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) Hr[m] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(Hd, 8 * t, 2048 * m, 0));
+        dft16<true>(v);
+        fft4096_mid_passes<true>(v, S, W2, w3, t);           // v[m] = X[t + 256 m]
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = cmul_pk(v[m], Hr[m]);
+        __builtin_amdgcn_sched_barrier(0);                  // (the requests must not be hoisted over the bins of H: same registers)
+        if (b + gridDim.x < nblk) request(b + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FOLD > 0) {
+            constexpr int DD = 1 << FOLD, NP = N >> FOLD, MP = 16 >> FOLD;     // decimation, inverse size, bins per lane
+            // bin t + 256 m folds onto t + 256 (m mod MP): inside the lane
+            f32x2_t *A = S, *B = S + NP;
+            const __amdgpu_buffer_rsrc_t Td = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(twiddle), 0, N * 8, 0x00020000);
+#pragma unroll
+            for (int mp = 0; mp < MP; ++mp) {
+                f32x2_t f = v[mp];
+#pragma unroll
+                for (int a = 1; a < DD; ++a) f = f + v[mp + a * MP];
+                A[t + 256 * mp] = f;
+            }
+            __syncthreads();
+            // (4096/D)-point backward transform, radix-4 Stockham passes (+ one radix-2) between the halves of S
+            f32x2_t *src = A, *dst = B;
+            int p = 1;
+            constexpr int T4 = NP >> 2;
+            while (p * 4 <= NP) {
+                const int tstep = (NP / (4 * p)) << FOLD;              // step in the 4096-entry twiddle table
+#pragma unroll 1
+                for (int i = t; i < T4; i += 256) {
+                    const int k = i & (p - 1);
+                    const int j = ((i - k) << 2) + k;
+                    const int m = k * tstep;
+                    f32x2_t u0 = src[i], u1 = src[i + T4], u2 = src[i + 2 * T4], u3 = src[i + 3 * T4];
+                    if (p > 1) {
+                        u1 = cmul_conj_pk(u1, __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(Td, 8 * m, 0, 0)));
+                        u2 = cmul_conj_pk(u2, __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(Td, 16 * m, 0, 0)));
+                        u3 = cmul_conj_pk(u3, __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(Td, 24 * m, 0, 0)));
+                    }
+                    radix4<false>(u0, u1, u2, u3);
+                    dst[j] = u0; dst[j + p] = u1; dst[j + 2 * p] = u2; dst[j + 3 * p] = u3;
                 }
-                radix4<false>(u0, u1, u2, u3);
-                dst[j] = u0; dst[j + p] = u1; dst[j + 2 * p] = u2; dst[j + 3 * p] = u3;
+                __syncthreads();
+                f32x2_t *tmp = src; src = dst; dst = tmp;
+                p <<= 2;
             }
-            __syncthreads();
-            float2 *tmp = src; src = dst; dst = tmp;
-            p <<= 2;
-        }
-        if (p < NP) {                                             // one radix-2 pass, p == NP/2
-            constexpr int T2 = NP >> 1;
-            for (int i = t; i < T2; i += 256) {
-                float2 u0 = src[i], u1 = src[i + T2];
-                if (p > 1) u1 = cmul2(u1, tw<false>(twiddle, (i & (p - 1)) << FOLD));
-                dst[i] = c_add(u0, u1);
-                dst[i + p] = c_sub(u0, u1);
+            if (p < NP) {                                             // one radix-2 pass, p == NP/2
+                constexpr int T2 = NP >> 1;
+#pragma unroll 1
+                for (int i = t; i < T2; i += 256) {
+                    f32x2_t u0 = src[i], u1 = src[i + T2];
+                    if (p > 1) u1 = cmul_conj_pk(u1, __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(Td, 8 * ((i & (p - 1)) << FOLD), 0, 0)));
+                    dst[i] = u0 + u1;
+                    dst[i + p] = u0 - u1;
+                }
+                __syncthreads();
+                f32x2_t *tmp = src; src = dst; dst = tmp;
             }
-            __syncthreads();
-            float2 *tmp = src; src = dst; dst = tmp;
-        }
-        const int nvalid = L >> FOLD;                             // outputs of this block
-        for (int r = t; r < nvalid; r += 256) {
-            const long long n = b * nvalid + r;
-            if (n < nout) {
-                if (REAL) ((float *)out_v)[n] = src[r].x;
-                else ((float2 *)out_v)[n] = src[r];
+            const int nvalid = L >> FOLD;                             // outputs of this block
+#pragma unroll 1
+            for (int r = t; r < nvalid; r += 256) {
+                const long long n = b * nvalid + r;
+                if (n < nout) {
+                    if (REAL) ((float *)out_v)[n] = src[r].x;
+                    else ((f32x2_t *)out_v)[n] = src[r];
+                }
             }
+            __syncthreads();                                          // S belongs to the next block from here
+            continue;
         }
-        return;
-    }
-    dft16<false>(v);                                     // inverse pass 1 on the same registers
-    fft4096_mid_passes<false>(v, S, twiddle, t);         // v[m] = z[t + 256 m]
+        dft16<false>(v);                                     // inverse pass 1 on the same registers
+        fft4096_mid_passes<false>(v, S, W2, w3, t);          // v[m] = z[t + 256 m]
+        if (decim == 1) {
+            // point t + 256 m is output b L + j, j = t + 256 m - (ntaps - 1), when 0 <= j < L: through a descriptor of
+            // the output stream (outputs past nout are out of its range), offsets of the other points out of range too
+            const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(out_v, 0, (int)(nout * (REAL ? 4 : 8)), 0x00020000);
+            const int j0 = t - (ntaps - 1);
+            const int ob = (int)((b * L + j0) * (REAL ? 4 : 8));
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int j = t + 256 * m - (ntaps - 1);         // offset of this point inside the block's outputs
-        if (j >= 0 && j < L && (j % decim) == 0) {
-            const long long n = (b * L + j) / decim;
-            if (n < nout) {
-                if (REAL) ((float *)out_v)[n] = v[m].x;
-                else ((float2 *)out_v)[n] = v[m];
+            for (int m = 0; m < 16; ++m) {
+                const int j = j0 + 256 * m;
+                const int off = (j >= 0 && j < L) ? ob + 256 * (REAL ? 4 : 8) * m : (int)0xfffffff0;
+                if (REAL) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[m].x), orr, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ols_u32x2, v[m]), orr, off, 0, 0);
+            }
+            continue;
+        }
+#pragma unroll 1
+        for (int m = 0; m < 16; ++m) {                       // any other decimation (rare here: 2, 4, 8, 16 fold)
+            const int j = t + 256 * m - (ntaps - 1);         // offset of this point inside the block's outputs
+            if (j >= 0 && j < L && (j % decim) == 0) {
+                const long long n = (b * L + j) / decim;
+                if (n < nout) {
+                    if (REAL) ((float *)out_v)[n] = v[m].x;
+                    else ((f32x2_t *)out_v)[n] = v[m];
+                }
             }
         }
     }
@@ -940,9 +1018,12 @@ static int launch_fftfilt4096_t(const void *in, long long nin, const void *hist,
                                 const float2 *H, void *out, long long nout, int decim, int L, int fold, hipStream_t st)
 {
     if (nout <= 0) return GRHIP_OK;
-    const unsigned nblk = (unsigned)((nin + L - 1) / L);
-#define GRHIP_OLS_LAUNCH(F) hipLaunchKernelGGL((fftfilt4096_kernel<REAL, F>), dim3(nblk), dim3(256), 0, st, in, nin, hist, ntaps, \
-                                               twiddle, H, out, nout, decim, L)
+    const long long nblk = (nin + L - 1) / L;
+    if (nin * (REAL ? 4 : 8) > 0x7fffffffLL) return fail(GRHIP_EINVAL, "overlap-save engine: more than 2 GB of input in one call");
+    const long long cap = 3LL * fft_num_cus();
+    const unsigned grid = (unsigned)(nblk < cap ? nblk : cap);
+#define GRHIP_OLS_LAUNCH(F) hipLaunchKernelGGL((fftfilt4096_kernel<REAL, F>), dim3(grid), dim3(256), 0, st, in, nin, hist, ntaps, \
+                                               twiddle, H, out, nout, decim, L, nblk)
     switch (fold) {
     case 1: GRHIP_OLS_LAUNCH(1); break;
     case 2: GRHIP_OLS_LAUNCH(2); break;

@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         tile_geom(s, bidx, rsrc, voff);
         fetch(rsrc, voff, -1);
     }
-    unsigned nn_q = 0;          // the queue's answer: valid in lane 0 of the workgroup only
+    unsigned nn_q = 0;          // the queue's raw answer (ticket number): valid in lane 0 of the workgroup only
     int voff_cur = 0;
     if (lead) {
         __amdgpu_buffer_rsrc_t rsrc;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
             }
             m = wave_max_nonneg(m);
             if (lane == 0) wmax[w] = m;
-            if (a.sched && t == 0) sched_slot[0] = nn_q;    // the queue's answer for the tile after next
+            if (a.sched && t == 0) sched_slot[0] = nn_q + 2u * Gd;    // the queue's answer for the tile after next
         }
         MF_STAMP(0);
         __syncthreads();        // planes free (previous tile's operand reads done), maxima and slot visible
@@ -350,7 +350,8 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         __amdgpu_buffer_rsrc_t rsrc_n; int voff_n;
         tile_geom(s_nxt, b_nxt, rsrc_n, voff_n);
         if (nxt >= total_tiles) voff_n = 0x7ffff000 - NI * 16 * mf::THREADS;     // out of range: zeros, no traffic
-        if (a.sched && t == 0) nn_q = atomicAdd(a.sched, 1u) + 2u * Gd;        // arrives long before it is needed
+        // (the ticket is used as it comes back, a tile later: arithmetic on it here would make wave 0 wait for the round trip)
+        if (a.sched && t == 0) nn_q = atomicAdd(a.sched, 1u);
 
         // output of this tile's stream, through a buffer descriptor: a store whose offset is out of
         // range (past the end of the stream; or made so for the lanes that own no output) is dropped

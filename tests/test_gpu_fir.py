@@ -72,6 +72,28 @@ def test_fir_fast_mode_tolerance(gpu, po, kind, ntaps, decim):
     assert np.abs(got - ref).max() <= TOL * max(np.abs(ref).max(), 1e-3 * bound)
 
 
+@pytest.mark.parametrize("kind,ntaps,decim,n", [("ccc", 1100, 1, 3_300_000), ("ccc", 600, 4, 1_400_000), ("ccc", 200, 3, 1_500_000),
+                                                ("fff", 1500, 1, 4_000_000), ("fff", 500, 8, 700_000)])
+def test_overlap_save_engine_persistent_walk(gpu, po, kind, ntaps, decim, n):
+    """more 4096-point blocks than resident workgroups (three per CU): every workgroup walks several blocks with the next
+    block's points in flight; full-size inverse with decimation 1 (descriptor stores) and 3 (generic), folded inverse at
+    4 and 8, complex and real data; every output against the oracle's direct form"""
+    rng = np.random.default_rng(ntaps + decim)
+    nin = n * decim + ntaps - 1
+    if kind == "ccc":
+        x = _rand_c(rng, nin)
+        taps = _rand_c(rng, ntaps) / np.float32(ntaps ** 0.5)
+        blk, ref = gpu.fir_filter_ccc(decim, taps), po.fir_ccc(taps, x, n, decim)
+    else:
+        x = rng.uniform(-1, 1, nin).astype(np.float32)
+        taps = (rng.uniform(-1, 1, ntaps) / ntaps ** 0.5).astype(np.float32)
+        blk, ref = gpu.fir_filter_fff(decim, taps), po.fir_fff(taps, x, n, decim)
+    blk.set_mode(gpu.MODE_FAST)
+    got = blk.work(n, x)
+    err = np.abs(got - ref)
+    assert err.max() <= TOL * np.abs(ref).max(), (int(err.argmax()), float(err.max()), float(np.abs(ref).max()))
+
+
 def test_fir_integer_data_exact_all_modes(gpu, po):
     """integer-valued data: every summation order is exact
     (filter/qa_gr_fir_ccf.cc:103-159 uses the same trick)"""

@@ -23,6 +23,7 @@ PY
     echo "$name done" >> $O/progress.log
 }
 run chain1024 $R/tools/bench_chain.py 1024
+run chain1536 $R/tools/bench_chain.py 1536
 run chain64 $R/tools/bench_chain.py 64
 run blocks $R/tools/bench_blocks.py
 run cfg3 $R/tools/bench_cfg3.py
