@@ -820,23 +820,18 @@ fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__r
         const long long base = b * L - (ntaps - 1);          // stream index of block position 0
         // Offsets: the hardware's range check looks at vector offset + immediate, not at the scalar offset, and a NEGATIVE
         // vector offset whose immediate brings it back into range does not come out as the in-range load it is (measured:
-        // the stream's first sample read as zero).  So the whole offset goes into the VGPR, and in the blocks that start
-        // before the stream (b L < ntaps - 1: one or two per call) the positions before it get an explicit out-of-range
-        // offset through a select, which also keeps the compiler from splitting the sum into register + immediate.
-        const int vo = (int)((base + t) * (REAL ? 4 : 8));
-        if (base < 0) {
+        // the stream's first sample read as zero).  So the whole offset goes into the VGPR, and the positions before the
+        // stream (blocks with b L < ntaps - 1: one or two per call) get an explicit out-of-range
+        // offset through a select (in every block: it also keeps the compiler from splitting the sum into register + immediate).
+        int tq = t;
+        asm volatile("" : "+v"(tq));                         // (recomputed per block: hoisted out of the loop, the sixteen offsets spill)
+        const int vo = ((int)base + tq) * (REAL ? 4 : 8);
+        const int first = base < 0 ? (int)-base : 0;         // block positions below this one lie before the stream
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int off = (base + t + 256 * q >= 0) ? vo + 256 * (REAL ? 4 : 8) * q : 0x7ffffff0;
-                if (REAL) pre[q] = f32x2_t{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0)), 0.f};
-                else pre[q] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                if (REAL) pre[q] = f32x2_t{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo + 256 * 4 * q, 0, 0)), 0.f};
-                else pre[q] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(xr, vo + 256 * 8 * q, 0, 0));
-            }
+        for (int q = 0; q < 16; ++q) {
+            const int off = (tq + 256 * q >= first) ? vo + 256 * (REAL ? 4 : 8) * q : 0x7ffffff0;
+            if (REAL) pre[q] = f32x2_t{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0)), 0.f};
+            else pre[q] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
         }
     };
     long long b = blockIdx.x;
@@ -869,10 +864,12 @@ fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__r
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = cmul_pk(v[m], Hr[m]);
         __builtin_amdgcn_sched_barrier(0);                  // (the requests must not be hoisted over the bins of H: same registers)
-        if (b + gridDim.x < nblk) request(b + gridDim.x);
+        if (FOLD == 0 && b + gridDim.x < nblk) request(b + gridDim.x);
         __builtin_amdgcn_sched_barrier(0);
         if (FOLD > 0) {
             constexpr int DD = 1 << FOLD, NP = N >> FOLD, MP = 16 >> FOLD;     // decimation, inverse size, bins per lane
+            int tf = t;
+            asm volatile("" : "+v"(tf));                                    // (index arithmetic per block, not hoisted and spilled)
             // bin t + 256 m folds onto t + 256 (m mod MP): inside the lane
             f32x2_t *A = S, *B = S + NP;
             const __amdgpu_buffer_rsrc_t Td = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(twiddle), 0, N * 8, 0x00020000);
@@ -881,9 +878,11 @@ fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__r
                 f32x2_t f = v[mp];
 #pragma unroll
                 for (int a = 1; a < DD; ++a) f = f + v[mp + a * MP];
-                A[t + 256 * mp] = f;
+                A[tf + 256 * mp] = f;
             }
             __syncthreads();
+            if (b + gridDim.x < nblk) request(b + gridDim.x);       // (the spectrum has left its registers)
+            __builtin_amdgcn_sched_barrier(0);
             // (4096/D)-point backward transform, radix-4 Stockham passes (+ one radix-2) between the halves of S
             f32x2_t *src = A, *dst = B;
             int p = 1;
@@ -891,7 +890,7 @@ fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__r
             while (p * 4 <= NP) {
                 const int tstep = (NP / (4 * p)) << FOLD;              // step in the 4096-entry twiddle table
 #pragma unroll 1
-                for (int i = t; i < T4; i += 256) {
+                for (int i = tf; i < T4; i += 256) {
                     const int k = i & (p - 1);
                     const int j = ((i - k) << 2) + k;
                     const int m = k * tstep;
@@ -911,7 +910,7 @@ fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__r
             if (p < NP) {                                             // one radix-2 pass, p == NP/2
                 constexpr int T2 = NP >> 1;
 #pragma unroll 1
-                for (int i = t; i < T2; i += 256) {
+                for (int i = tf; i < T2; i += 256) {
                     f32x2_t u0 = src[i], u1 = src[i + T2];
                     if (p > 1) u1 = cmul_conj_pk(u1, __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(Td, 8 * ((i & (p - 1)) << FOLD), 0, 0)));
                     dst[i] = u0 + u1;
@@ -922,7 +921,7 @@ fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__r
             }
             const int nvalid = L >> FOLD;                             // outputs of this block
 #pragma unroll 1
-            for (int r = t; r < nvalid; r += 256) {
+            for (int r = tf; r < nvalid; r += 256) {
                 const long long n = b * nvalid + r;
                 if (n < nout) {
                     if (REAL) ((float *)out_v)[n] = src[r].x;
