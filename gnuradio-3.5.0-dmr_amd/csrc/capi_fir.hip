@@ -71,7 +71,24 @@ static bool hidec_wanted(int decim, int ntaps, bool ctaps, bool have_ols)
     // component, twice for complex taps, over the share of lanes a tile keeps busy
     const int tn = hidec_outputs_per_tile(decim, ntaps);
     const double cost = (double)ntaps / decim * (ctaps ? 2.0 : 1.0) * 512.0 / (tn < 512 ? tn : 512);
-    return cost <= 110.0;
+    // round 2 (profiles/r02_decim_engines.log): the engine is 2.3x faster than in round 1, fastest where its inverse
+    // folds (decimation 8, 16)
+    return cost <= ((decim == 8 || decim == 16) ? 24.0 : 42.0);
+}
+
+// Taps per polyphase component above which the overlap-save engine takes over from the tiled vector kernel (single-stream
+// calls).  Measured on MI355X (tools/bench_ols_crossover.py, profiles/r02_ols_crossover.log): the tiled kernel runs at
+// about 15000 / (taps per phase) Gsamples/s with real taps and half that with complex taps, the engine (round 2:
+// persistent, resident twiddles) at 230-290 whatever the filter.
+static int ols_crossover(bool complex_taps, int decim)
+{
+#ifdef GRHIP_DIAG       // diagnostic builds only: GRHIP_OLS_MIN = threshold for both kinds (0 = engine wherever it can, 9999 = never)
+    if (const char *e = getenv("GRHIP_OLS_MIN")) return atoi(e);
+#endif
+    // measured crossovers (taps per phase): real taps 48 / 60 / 28 at decimation 1 / 2 / 4, complex taps 40 / 40 / 26
+    // (the engine's folded inverse makes it fastest at 4, the full-size inverse of decimation 1 comes next)
+    if (complex_taps) return decim >= 4 ? 26 : 40;
+    return decim >= 4 ? 28 : decim == 2 ? 60 : 48;
 }
 
 int XlatingCore::build(int device)
@@ -187,7 +204,7 @@ int XlatingCore::build(int device)
         use_ols = true;
     }
     // same crossover as gr_fir_filter (see there); single-stream calls only, batched launches stay tiled
-    prefer_ols = use_ols && (!use_tiled || ntaps / decim > 120);
+    prefer_ols = use_ols && (!use_tiled || ntaps / decim > ols_crossover(!real_proto, decim));
     // real prototype: pre-mix form, half the FMAs for one more multiply per staged sample -- pays from about 16
     // taps per polyphase component (tools/bench_decim.py)
     hidec_premix = real_proto && ntaps > 0 && ntaps / decim >= 16;
@@ -495,9 +512,7 @@ struct grhip_fir_filter : HandleBase {
             if (rc) return rc;
             use_ols = true;
         }
-        // Measured on MI355X (profiles/r01_blocks_bench.log): the tiled kernel runs at about
-        // 15000 / (taps per phase) Gsamples/s, the overlap-save engine at about 125 whatever the filter:
-        // fast convolution takes over above ~120 taps per phase.
+        // (crossover between the tiled kernel and the overlap-save engine: ols_crossover above)
         use_hidec = !use_tiled && kind != FIR_FFF && hidec_wanted(decim, ntaps, kind == FIR_CCC, use_ols);
         if (use_hidec) {
             std::vector<float> hp2;
@@ -506,7 +521,7 @@ struct grhip_fir_filter : HandleBase {
             if (rc) return rc;
         }
         // (float data: the engine only where the float-pair mode of the tiled kernel does not reach)
-        prefer_ols = use_ols && (!use_tiled || (kind != FIR_FFF && ntaps / decim > 120));
+        prefer_ols = use_ols && (!use_tiled || (kind != FIR_FFF && ntaps / decim > ols_crossover(kind == FIR_CCC, decim)));
         return GRHIP_OK;
     }
 
