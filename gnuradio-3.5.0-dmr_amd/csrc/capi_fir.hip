@@ -203,8 +203,10 @@ int XlatingCore::build(int device)
         if (rc) return rc;
         use_ols = true;
     }
-    // same crossover as gr_fir_filter (see there); single-stream calls only, batched launches stay tiled
-    prefer_ols = use_ols && (!use_tiled || ntaps / decim > ols_crossover(!real_proto, decim));
+    // single-stream calls only, batched launches stay tiled.  Not gr_fir_filter's crossover: behind the engine this block
+    // still needs the rotator-table multiply and (fused form) the stand-alone demodulator as passes of their own, which
+    // the tiled kernel does in its epilogue -- the round-1 crossover stays (and the matrix-core engine comes first anyway)
+    prefer_ols = use_ols && (!use_tiled || ntaps / decim > 120);
     // real prototype: pre-mix form, half the FMAs for one more multiply per staged sample -- pays from about 16
     // taps per polyphase component (tools/bench_decim.py)
     hidec_premix = real_proto && ntaps > 0 && ntaps / decim >= 16;
@@ -520,8 +522,9 @@ struct grhip_fir_filter : HandleBase {
             rc = upload(d_hidec_taps, hp2.data(), hp2.size() * sizeof(float));
             if (rc) return rc;
         }
-        // (float data: the engine only where the float-pair mode of the tiled kernel does not reach)
-        prefer_ols = use_ols && (!use_tiled || (kind != FIR_FFF && ntaps / decim > ols_crossover(kind == FIR_CCC, decim)));
+        // (float data: the tiled kernel's float-pair mode runs at about 50000 / taps Gsamples/s, the real-data engine at
+        // 250-290: the engine where the float-pair mode does not reach, and from 176 taps per phase on)
+        prefer_ols = use_ols && (!use_tiled || ntaps / decim > (kind == FIR_FFF ? 176 : ols_crossover(kind == FIR_CCC, decim)));
         return GRHIP_OK;
     }
 

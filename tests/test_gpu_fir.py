@@ -447,7 +447,7 @@ def test_fir_fff_fast_mode(gpu, po, ntaps, decim, n):
     xi = rng.integers(-8, 8, nin).astype(np.float32)
     ti = rng.integers(-4, 4, ntaps).astype(np.float32)
     blk2 = gpu.fir_filter_fff(decim, ti)
-    engine = ntaps >= 48 and (decim > 2 or ntaps > 1024)
+    engine = ntaps >= 48 and (decim > 2 or ntaps > 1024 or ntaps // decim > 176)
     gi, ri = blk2.work(n, xi), po.fir_fff(ti, xi, n, decim)
     if engine:
         assert np.abs(gi - ri).max() <= TOL * np.abs(ri).max()

@@ -59,7 +59,7 @@ n = 128_000_000
 xf = torch.randn(n + 256, device=dev)
 yf = torch.empty(n, device=dev)
 blk = g.fir_filter_fff(1, wl.lowpass_taps(256, 0.1, 1.0))
-report("fir_filter_fff 256t D=1 FAST (tiled kernel, float-pair mode)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=20), n, 8)
+report("fir_filter_fff 256t D=1 FAST (real-data overlap-save engine since round 2; round 1: tiled kernel, float-pair mode)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=20), n, 8)
 blk.set_mode(g.MODE_GENERIC)
 report("fir_filter_fff 256t D=1 GENERIC (bit-exact order)", timeit(lambda: blk.work_device(n, xf, yf, st), reps=20), n, 8)
 
@@ -144,7 +144,7 @@ report("fir_filter_ccc 1000t D=1 FAST (dispatches to the overlap-save engine)", 
 blk4 = g.fir_filter_ccf(1, wl.lowpass_taps(256, 0.1, 1.0))
 report("fir_filter_ccf 256t D=1 FAST (overlap-save engine: 256 taps per phase)", timeit(lambda: blk4.work_device(n, x, y, st), reps=10), n, 16)
 blk5 = g.fir_filter_ccf(1, wl.lowpass_taps(128, 0.1, 1.0))
-report("fir_filter_ccf 128t D=1 FAST (tiled kernel)", timeit(lambda: blk5.work_device(n, x, y, st), reps=10), n, 16)
+report("fir_filter_ccf 128t D=1 FAST (overlap-save engine since round 2; round 1: tiled kernel)", timeit(lambda: blk5.work_device(n, x, y, st), reps=10), n, 16)
 
 # freq_xlating_fir_filter_ccc at decimations the tiled kernel does not take: high-decimation direct kernel + rotator
 # (tools/bench_decim.py compares it with the overlap-save engine shape by shape)
@@ -154,10 +154,10 @@ y = torch.empty((n // 20, 2), device=dev)
 blk = g.freq_xlating_fir_filter_ccc(20, wl.lowpass_taps(400, 0.02, 1.0).astype(np.complex64), c["center_freq"], c["fs"])
 def run_xl20():
     blk.reset(); blk.work_device(n // 20, x, y, st)
-report("freq_xlating_fir_filter_ccc 400t D=20 (high-decimation direct kernel)", timeit(run_xl20, reps=10), n, 8.4)
+report("freq_xlating_fir_filter_ccc 400t D=20 real prototype (high-decimation direct kernel, pre-mix form)", timeit(run_xl20, reps=10), n, 8.4)
 
 y16 = torch.empty((n // 16, 2), device=dev)
 blk16 = g.freq_xlating_fir_filter_ccc(16, wl.lowpass_taps(400, 0.02, 1.0).astype(np.complex64), c["center_freq"], c["fs"])
 def run_xl16():
     blk16.reset(); blk16.work_device(n // 16, x, y16, st)
-report("freq_xlating_fir_filter_ccc 400t D=16 (high-decimation direct kernel)", timeit(run_xl16, reps=10), n, 8.5)
+report("freq_xlating_fir_filter_ccc 400t D=16 real prototype (overlap-save engine, folded inverse; round 1: direct kernel)", timeit(run_xl16, reps=10), n, 8.5)
