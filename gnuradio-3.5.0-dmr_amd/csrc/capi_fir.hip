@@ -205,8 +205,10 @@ int XlatingCore::build(int device)
     }
     // single-stream calls only, batched launches stay tiled.  Not gr_fir_filter's crossover: behind the engine this block
     // still needs the rotator-table multiply and (fused form) the stand-alone demodulator as passes of their own, which
-    // the tiled kernel does in its epilogue -- the round-1 crossover stays (and the matrix-core engine comes first anyway)
-    prefer_ols = use_ols && (!use_tiled || ntaps / decim > 120);
+    // the tiled kernel does in its epilogue -- the round-1 crossover stays for real prototypes (the matrix-core engine
+    // comes first there anyway); complex prototypes cost the tiled kernel twice the FMAs: measured 190 (tiled) against
+    // 226 Gsamples/s (engine + rotator pass) at 64 taps per phase, D = 4
+    prefer_ols = use_ols && (!use_tiled || ntaps / decim > (real_proto ? 120 : 56));
     // real prototype: pre-mix form, half the FMAs for one more multiply per staged sample -- pays from about 16
     // taps per polyphase component (tools/bench_decim.py)
     hidec_premix = real_proto && ntaps > 0 && ntaps / decim >= 16;
