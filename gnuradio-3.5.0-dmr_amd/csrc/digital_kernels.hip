@@ -355,6 +355,14 @@ int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipSt
 constexpr int CORR_TB = 8192;     // outputs per workgroup (4 rounds of 8 per lane)
 constexpr int CORR_WORDS = CORR_TB / 64 + 2;
 
+#ifndef GRHIP_CORR_TPW
+#define GRHIP_CORR_TPW 4
+#endif
+constexpr int CORR_TPW = GRHIP_CORR_TPW;        // consecutive tiles per workgroup
+
+// One workgroup walks CORR_TPW consecutive tiles of a stream; the loads of the next tile (interior tiles: 16-byte loads
+// kept in registers) are issued before the current tile is packed and evaluated, so HBM latency runs under the bit work.
+template <bool SOFT>        // SOFT: float items in (the slicer fused), else bytes
 __global__ void __launch_bounds__(256)
 corr_kernel(CorrParams p, const CorrState *__restrict__ state_in, const unsigned char *__restrict__ in_bytes,
             const float *__restrict__ in_soft, long long in_stride, unsigned char *__restrict__ out,
@@ -364,132 +372,155 @@ corr_kernel(CorrParams p, const CorrState *__restrict__ state_in, const unsigned
     const int s = blockIdx.y, t = threadIdx.x;
     long long n = n_arg;
     if (n_ptr) { long long m = n_ptr[(long long)s * n_ptr_stride]; n = m < n ? m : n; }
-    const long long i0 = (long long)blockIdx.x * CORR_TB;
-    if (i0 >= n) return;
-    const unsigned char *__restrict__ xb = in_bytes ? in_bytes + (long long)s * in_stride : nullptr;
-    const float *__restrict__ xf = in_soft ? in_soft + (long long)s * in_stride : nullptr;
+    const long long tile0 = (long long)blockIdx.x * CORR_TPW;
+    if (tile0 * CORR_TB >= n) return;
+    const unsigned char *__restrict__ xb = !SOFT ? in_bytes + (long long)s * in_stride : nullptr;
+    const float *__restrict__ xf = SOFT ? in_soft + (long long)s * in_stride : nullptr;
     const CorrState st = state_in[s];
     if (t == 0) P[CORR_WORDS] = 0;      // slack word (read by the look-ahead, its bits are never used)
-
-    // words i0/64 - 2 .. i0/64 + CORR_TB/64 - 1, first item of a word at its MSB.
-    // Wide path: a lane takes 16 input bytes (or 8 floats) with 16-byte loads, squeezes
-    // their LSBs (sign decisions) into one 16-bit (8-bit) chunk with a multiply, and
-    // drops the chunk into its place inside the 64-bit word (little-endian LDS: chunk c
-    // of a word lives at sub-index last-c).  All loads of a lane are issued before the
-    // first is used.
-    const long long wlo = i0 / 64 - 2;
-    const long long base = wlo * 64;                    // first item covered by P (may be < 0)
-    const bool wide = (base >= 0) && (base + (long long)CORR_WORDS * 64 <= n) &&
-                      ((((uintptr_t)(xb ? (const void *)(xb + base) : (const void *)(xf + base))) & 15) == 0);
-    if (wide && xb) {
-        constexpr int NCH = CORR_WORDS * 4;             // 16-item chunks
-        constexpr int PER = (NCH + 255) / 256;
-        uint4 v[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int c = t + 256 * k;
-            v[k] = (c < NCH) ? reinterpret_cast<const uint4 *>(xb + base)[c] : make_uint4(0, 0, 0, 0);
-        }
-        unsigned short *P16 = reinterpret_cast<unsigned short *>(P);
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int c = t + 256 * k;
-            if (c < NCH) {
-                // ((w & 0x01010101) * 0x08040201) >> 24 : LSBs of bytes 0..3 -> bits 3..0
-                const unsigned n0 = (((v[k].x & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
-                const unsigned n1 = (((v[k].y & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
-                const unsigned n2 = (((v[k].z & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
-                const unsigned n3 = (((v[k].w & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
-                P16[(c & ~3) + (3 - (c & 3))] = (unsigned short)((n0 << 12) | (n1 << 8) | (n2 << 4) | n3);
-            }
-        }
-    } else if (wide && xf) {
-        constexpr int NCH = CORR_WORDS * 8;             // 8-item chunks
-        constexpr int PER = (NCH + 255) / 256;
-        float4 v[2 * PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int c = t + 256 * k;
-            const float4 *src = reinterpret_cast<const float4 *>(xf + base) + 2 * (c < NCH ? c : 0);
-            v[2 * k] = src[0];
-            v[2 * k + 1] = src[1];
-        }
-        unsigned char *P8 = reinterpret_cast<unsigned char *>(P);
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int c = t + 256 * k;
-            if (c < NCH) {
-                const float4 a0 = v[2 * k], a1 = v[2 * k + 1];
-                const unsigned b = ((a0.x >= 0) << 7) | ((a0.y >= 0) << 6) | ((a0.z >= 0) << 5) | ((a0.w >= 0) << 4) |
-                                   ((a1.x >= 0) << 3) | ((a1.y >= 0) << 2) | ((a1.z >= 0) << 1) | (a1.w >= 0);
-                P8[(c & ~7) + (7 - (c & 7))] = (unsigned char)b;
-            }
-        }
-    } else {
-        // first / last tile of a stream, or unaligned input: one item per lane, wave ballot
-        for (int wi = t >> 6; wi < CORR_WORDS; wi += 4) {
-            long long w = wlo + wi;
-            long long idx = w * 64 + (t & 63);
-            int bit = 0;
-            if (idx >= 0 && idx < n) bit = xb ? (xb[idx] & 1) : (xf[idx] >= 0 ? 1 : 0);
-            unsigned long long m = __ballot(bit);            // lane l -> bit l
-            if ((t & 63) == 0) P[wi] = __brevll(m);          // first item at the MSB
-        }
-    }
-    __syncthreads();
-
-    // words before the call: w = -1 is the shift register carried in, older ones are zero
-    // (the ballot path above has packed zeros there; only the first tile of a stream has them)
-    if (i0 == 0) {
-        if (t == 0) P[1] = st.data_reg;
-        __syncthreads();
-    }
     const unsigned chi = (unsigned)(p.access_code >> 32), clo = (unsigned)p.access_code;
     const unsigned mhi = (unsigned)(p.mask >> 32), mlo = (unsigned)p.mask;
-
-    // A lane emits 8 consecutive outputs per round.  Their bit 0 is one byte of one packed
-    // word; their flags come from ONE 64-bit window that slides by a bit per output
-    // (two 32-bit halves: a funnel shift and a shift-or), instead of re-assembling the
-    // window from LDS for every output.
     unsigned char *__restrict__ y = out + (long long)s * out_stride;
-    for (int rnd = 0; rnd < CORR_TB / 2048; ++rnd) {
-        const long long o0 = i0 + 2048ll * rnd + 8 * t;
-        if (o0 >= n) break;
-        // bit 0 of outputs o0 .. o0+7: stream bits o0-64 .. o0-57 (same word, byte aligned)
-        const long long b0 = o0 - 64;
-        const unsigned byte0 = (unsigned)(P[(b0 >> 6) - wlo] >> (56 - (int)(b0 & 63))) & 0xFFu;
-        // window of output o0: stream bits k0-64 .. k0-1, k0 = o0 - len; then bits k0 .. k0+6 slide in
-        const long long k0 = o0 - (long long)p.len;
-        const long long wk = k0 >> 6;                          // floor division (arithmetic shift)
-        const int rk = (int)(k0 & 63);
-        const unsigned long long hi = P[wk - 1 - wlo], lo = P[wk - wlo], nx = P[wk + 1 - wlo];
-        const unsigned long long W0 = rk ? (hi << rk) | (lo >> (64 - rk)) : hi;
-        const unsigned nb = (unsigned)((rk ? (lo << rk) | (nx >> (64 - rk)) : lo) >> 56);
-        unsigned whi = (unsigned)(W0 >> 32), wlo32 = (unsigned)W0;
-        unsigned out_lo = 0, out_hi = 0;
+
+    // words i0/64 - 2 .. i0/64 + CORR_TB/64 - 1 of a tile, first item of a word at its MSB.
+    // Wide path (interior tiles, 16-byte aligned): a lane takes 16 input bytes (or 8 floats) with 16-byte loads, squeezes
+    // their LSBs (sign decisions) into one 16-bit (8-bit) chunk with a multiply, and drops the chunk into its place inside
+    // the 64-bit word (little-endian LDS: chunk c of a word lives at sub-index last-c).
+    constexpr int NCHB = CORR_WORDS * 4, PERB = (NCHB + 255) / 256;       // 16-item chunks (bytes)
+    constexpr int NCHF = CORR_WORDS * 8, PERF = (NCHF + 255) / 256;       // 8-item chunks (floats)
+    uint4 vb[SOFT ? 1 : PERB];
+    float4 vf[SOFT ? 2 * PERF : 1];
+    auto is_wide = [&](long long i0) -> bool {
+        const long long base = (i0 / 64 - 2) * 64;
+        return (base >= 0) && (base + (long long)CORR_WORDS * 64 <= n) &&
+               ((((uintptr_t)(xb ? (const void *)(xb + base) : (const void *)(xf + base))) & 15) == 0);
+    };
+    auto request = [&](long long i0) __attribute__((always_inline)) {
+        const long long base = (i0 / 64 - 2) * 64;
+        if (!SOFT) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            unsigned o = (byte0 >> (7 - j)) & 1u;
-            const unsigned nwrong = (unsigned)__popc((whi ^ chi) & mhi) + (unsigned)__popc((wlo32 ^ clo) & mlo);
-            if (nwrong <= p.threshold && k0 + j >= 0 && p.len > 0) o |= 2u;
-            whi = (whi << 1) | (wlo32 >> 31);
-            wlo32 = (wlo32 << 1) | ((nb >> (7 - j)) & 1u);
-            if (j < 4) out_lo |= o << (8 * j); else out_hi |= o << (8 * (j - 4));
-        }
-        if (o0 < 64) {          // flags already in flight at call start
+            for (int k = 0; k < PERB; ++k) {
+                const int c = t + 256 * k;
+                vb[k] = (c < NCHB) ? reinterpret_cast<const uint4 *>(xb + base)[c] : make_uint4(0, 0, 0, 0);
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned f = (unsigned)((st.flag_reg >> (63 - (int)(o0 + j))) & 1ull) << 1;
-                if (j < 4) out_lo |= f << (8 * j); else out_hi |= f << (8 * (j - 4));
+            for (int k = 0; k < PERF; ++k) {
+                const int c = t + 256 * k;
+                const float4 *src = reinterpret_cast<const float4 *>(xf + base) + 2 * (c < NCHF ? c : 0);
+                vf[2 * k] = src[0];
+                vf[2 * k + 1] = src[1];
             }
         }
-        if (o0 + 8 <= n && ((((uintptr_t)(y + o0)) & 7) == 0)) {
-            *reinterpret_cast<uint2 *>(y + o0) = make_uint2(out_lo, out_hi);
+    };
+    bool wide = is_wide(tile0 * CORR_TB);
+    if (wide) request(tile0 * CORR_TB);
+
+    for (int ti = 0; ti < CORR_TPW; ++ti) {
+        const long long i0 = (tile0 + ti) * CORR_TB;
+        if (i0 >= n) break;
+        const long long wlo = i0 / 64 - 2;
+        if (wide && !SOFT) {
+            unsigned short *P16 = reinterpret_cast<unsigned short *>(P);
+#pragma unroll
+            for (int k = 0; k < PERB; ++k) {
+                const int c = t + 256 * k;
+                if (c < NCHB) {
+                    // ((w & 0x01010101) * 0x08040201) >> 24 : LSBs of bytes 0..3 -> bits 3..0
+                    const unsigned n0 = (((vb[k].x & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
+                    const unsigned n1 = (((vb[k].y & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
+                    const unsigned n2 = (((vb[k].z & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
+                    const unsigned n3 = (((vb[k].w & 0x01010101u) * 0x08040201u) >> 24) & 0xFu;
+                    P16[(c & ~3) + (3 - (c & 3))] = (unsigned short)((n0 << 12) | (n1 << 8) | (n2 << 4) | n3);
+                }
+            }
+        } else if (wide && SOFT) {
+            unsigned char *P8 = reinterpret_cast<unsigned char *>(P);
+#pragma unroll
+            for (int k = 0; k < PERF; ++k) {
+                const int c = t + 256 * k;
+                if (c < NCHF) {
+                    const float4 a0 = vf[2 * k], a1 = vf[2 * k + 1];
+                    const unsigned b = ((a0.x >= 0) << 7) | ((a0.y >= 0) << 6) | ((a0.z >= 0) << 5) | ((a0.w >= 0) << 4) |
+                                       ((a1.x >= 0) << 3) | ((a1.y >= 0) << 2) | ((a1.z >= 0) << 1) | (a1.w >= 0);
+                    P8[(c & ~7) + (7 - (c & 7))] = (unsigned char)b;
+                }
+            }
         } else {
-            const unsigned long long packed = ((unsigned long long)out_hi << 32) | out_lo;
-            for (int j = 0; j < 8; ++j)
-                if (o0 + j < n) y[o0 + j] = (unsigned char)(packed >> (8 * j));
+            // first / last tile of a stream, or unaligned input: one item per lane, wave ballot
+            for (int wi = t >> 6; wi < CORR_WORDS; wi += 4) {
+                long long w = wlo + wi;
+                long long idx = w * 64 + (t & 63);
+                int bit = 0;
+                if (idx >= 0 && idx < n) bit = xb ? (xb[idx] & 1) : (xf[idx] >= 0 ? 1 : 0);
+                unsigned long long m = __ballot(bit);            // lane l -> bit l
+                if ((t & 63) == 0) P[wi] = __brevll(m);          // first item at the MSB
+            }
         }
+        // the next tile's loads fly under this tile's bit work
+        {
+            const long long i1 = i0 + CORR_TB;
+            wide = ti + 1 < CORR_TPW && i1 < n && is_wide(i1);
+            if (wide) request(i1);
+        }
+        __syncthreads();
+
+        // words before the call: w = -1 is the shift register carried in, older ones are zero
+        // (the ballot path above has packed zeros there; only the first tile of a stream has them)
+        if (i0 == 0) {
+            if (t == 0) P[1] = st.data_reg;
+            __syncthreads();
+        }
+
+        // A lane emits 8 consecutive outputs per round.  Their bit 0 is one byte of one packed
+        // word; their flags come from ONE 64-bit window that slides by a bit per output
+        // (two 32-bit halves: a funnel shift and a shift-or), instead of re-assembling the
+        // window from LDS for every output.
+        for (int rnd = 0; rnd < CORR_TB / 2048; ++rnd) {
+            const long long o0 = i0 + 2048ll * rnd + 8 * t;
+            if (o0 >= n) break;
+            // bit 0 of outputs o0 .. o0+7: stream bits o0-64 .. o0-57 (same word, byte aligned)
+            const long long b0 = o0 - 64;
+            const unsigned byte0 = (unsigned)(P[(b0 >> 6) - wlo] >> (56 - (int)(b0 & 63))) & 0xFFu;
+            // window of output o0: stream bits k0-64 .. k0-1, k0 = o0 - len; then bits k0 .. k0+6 slide in
+            const long long k0 = o0 - (long long)p.len;
+            const long long wk = k0 >> 6;                          // floor division (arithmetic shift)
+            const int rk = (int)(k0 & 63);
+            const unsigned long long hi = P[wk - 1 - wlo], lo = P[wk - wlo], nx = P[wk + 1 - wlo];
+            const unsigned long long W0 = rk ? (hi << rk) | (lo >> (64 - rk)) : hi;
+            const unsigned nb = (unsigned)((rk ? (lo << rk) | (nx >> (64 - rk)) : lo) >> 56);
+            // The eight windows are eight funnel shifts of (W0, next byte) by constant amounts -- no chain from one output to
+            // the next; a flag is a carry into an 8-bit accumulator (acc + acc + [nwrong <= thr]: bit 7-j = output j, the
+            // layout of byte0); both bytes are then spread to one bit per output byte with a multiply.
+            const unsigned whi0 = (unsigned)(W0 >> 32), wlo0 = (unsigned)W0, nbtop = nb << 24;
+            unsigned acc = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned wh = j ? __builtin_amdgcn_alignbit(whi0, wlo0, 32 - j) : whi0;
+                const unsigned wl = j ? __builtin_amdgcn_alignbit(wlo0, nbtop, 32 - j) : wlo0;
+                const unsigned nwrong = (unsigned)__popc((wh ^ chi) & mhi) + (unsigned)__popc((wl ^ clo) & mlo);
+                acc = acc + acc + (nwrong <= p.threshold ? 1u : 0u);
+            }
+            // positions before the stream (k0 + j < 0) raise no flag; nor does an empty code
+            const unsigned valid = (p.len == 0 || k0 <= -8) ? 0u : (k0 >= 0 ? 0xFFu : (0xFFu >> (unsigned)(-k0)));
+            acc &= valid;
+            if (o0 < 64)            // flags already in flight at call start: flag_reg bit 63 - (o0 + j) for output j
+                acc |= (unsigned)((st.flag_reg >> (56 - (int)o0)) & 0xFFull);
+            // four bits b3 b2 b1 b0 -> bytes (b3, b2, b1, b0) from the low byte up: the partial products of the multiply
+            // occupy disjoint bit ranges (no carries)
+            // (24-bit multiply: full rate; the fourth partial product is a shift)
+            auto spread4 = [](unsigned x4) { return (((__umul24(x4, 0x8040u)) | (x4 << 24)) & 0x01010100u) | (x4 >> 3); };
+            const unsigned out_lo = spread4(byte0 >> 4) | (spread4(acc >> 4) << 1);
+            const unsigned out_hi = spread4(byte0 & 15u) | (spread4(acc & 15u) << 1);
+            if (o0 + 8 <= n && ((((uintptr_t)(y + o0)) & 7) == 0)) {
+                *reinterpret_cast<uint2 *>(y + o0) = make_uint2(out_lo, out_hi);
+            } else {
+                const unsigned long long packed = ((unsigned long long)out_hi << 32) | out_lo;
+                for (int j = 0; j < 8; ++j)
+                    if (o0 + j < n) y[o0 + j] = (unsigned char)(packed >> (8 * j));
+            }
+        }
+        __syncthreads();            // P belongs to the next tile from here
     }
 }
 
@@ -512,14 +543,17 @@ corr_tail_kernel(CorrParams p, CorrState *__restrict__ state, const unsigned cha
         long long back = -1 - idx;                  // in[-1] is data_reg bit 0
         return back < 64 ? (st.data_reg >> back) & 1ull : 0ull;
     };
+    // The last 128 stream bits, two wave ballots (every lane loads two items, all in flight at once; a serial walk of 64
+    // dependent loads per lane cost 17 us per call): A = bits n-128 .. n-65, B = bits n-64 .. n-1, oldest at the MSB.
+    const unsigned long long A = __brevll(__ballot((int)bit_at(n - 128 + t)));
+    const unsigned long long B = __brevll(__ballot((int)bit_at(n - 64 + t)));
     // lane t evaluates the flag of position k = n - 1 - t (for t < len), which sits at
-    // flag_reg bit (64 - len) + t after n items.
+    // flag_reg bit (64 - len) + t after n items.  Its window, bits k-64 .. k-1, is (A:B) >> (t + 1).
     unsigned long long contrib = 0;
     if (t < (int)p.len) {
         long long k = n - 1 - t;
         if (k >= 0) {
-            unsigned long long W = 0;
-            for (int j = 0; j < 64; ++j) W = (W << 1) | bit_at(k - 64 + j);
+            const unsigned long long W = t == 63 ? A : (A << (63 - t)) | (B >> (t + 1));
             unsigned nwrong = (unsigned)__popcll((W ^ p.access_code) & p.mask);
             if (nwrong <= p.threshold) contrib = 1ull << (64 - p.len + t);
         }
@@ -531,11 +565,9 @@ corr_tail_kernel(CorrParams p, CorrState *__restrict__ state, const unsigned cha
         contrib = ((unsigned long long)hi << 32) | lo;
     }
     if (t == 0) {
-        unsigned long long d = 0;
-        for (int j = 0; j < 64; ++j) d = (d << 1) | bit_at(n - 64 + j);
         unsigned long long f = (n < 64) ? (st.flag_reg << n) : 0ull;
         CorrState ns;
-        ns.data_reg = d;
+        ns.data_reg = B;
         ns.flag_reg = f | contrib;
         state[s] = ns;
     }
@@ -546,9 +578,12 @@ int launch_correlate(const CorrParams &p, CorrState *state, int n_streams, const
                      long long n, const int *n_ptr, int n_ptr_stride, hipStream_t st)
 {
     if (n <= 0 || n_streams <= 0) return GRHIP_OK;
-    dim3 grid((unsigned)((n + CORR_TB - 1) / CORR_TB), (unsigned)n_streams);
-    hipLaunchKernelGGL(corr_kernel, grid, dim3(256), 0, st, p, (const CorrState *)state, in_bytes, in_soft,
-                       in_stride, out, out_stride, n, n_ptr, n_ptr_stride);
+    const long long per_wg = (long long)CORR_TB * CORR_TPW;
+    dim3 grid((unsigned)((n + per_wg - 1) / per_wg), (unsigned)n_streams);
+    if (in_bytes) hipLaunchKernelGGL(corr_kernel<false>, grid, dim3(256), 0, st, p, (const CorrState *)state, in_bytes, in_soft,
+                                     in_stride, out, out_stride, n, n_ptr, n_ptr_stride);
+    else hipLaunchKernelGGL(corr_kernel<true>, grid, dim3(256), 0, st, p, (const CorrState *)state, in_bytes, in_soft,
+                            in_stride, out, out_stride, n, n_ptr, n_ptr_stride);
     GRHIP_HIP(hipGetLastError());
     hipLaunchKernelGGL(corr_tail_kernel, dim3(n_streams), dim3(64), 0, st, p, state, in_bytes, in_soft,
                        in_stride, n, n_ptr, n_ptr_stride);
