@@ -128,6 +128,36 @@ def test_correlator_random_bit_exact(gpu, po, L, thr):
     assert (ref & 2).any() or L > 60
 
 
+@pytest.mark.parametrize("shift", [0, 1, 5, 16])
+def test_correlator_long_stream_any_alignment(gpu, po, shift):
+    """a million items through the device entry: workgroups walk four tiles each with the next tile's loads in flight;
+    a stream that starts off a 16-byte boundary takes the ballot path in every tile; two calls on the same handle (the
+    state between them now comes from two ballots over the last 128 bits)"""
+    import torch
+    rng = np.random.default_rng(500 + shift)
+    code = rng.integers(0, 2, 48)
+    n = 1_000_003
+    bits = rng.integers(0, 2, n).astype(np.uint8)
+    for pos in rng.integers(0, n - 48, 400):
+        bits[pos:pos + 48] = code
+    bits[n // 2 - 20:n // 2 + 28] = code          # straddles the split between the two calls
+    s = "".join(map(str, code))
+    ref = po.CorrelateAccessCode(s, 1).work(bits)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    d_in = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    d_in[shift:shift + n] = torch.from_numpy(bits).to(dev)
+    d_out = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    blk = gpu.correlate_access_code_bb(s, 1)
+    h = n // 2
+    assert blk.work_device(h, d_in[shift:], d_out[shift:], st) == h
+    assert blk.work_device(n - h, d_in[shift + h:], d_out[shift + h:], st) == n - h
+    st.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[shift:shift + n], ref)
+    assert not got[:shift].any() and not got[shift + n:].any()
+
+
 def test_correlator_state_across_calls(gpu, po):
     """d_data_reg / d_flag_reg carried across work() calls, at every alignment"""
     rng = np.random.default_rng(77)
@@ -272,3 +302,20 @@ def test_binary_slicer_vector_and_tail_paths(gpu, po):
     assert blk.work_device(4999, d[1:], o[1:], st) == 4999           # both pointers off the 16-byte grid
     st.synchronize()
     assert np.array_equal(o[1:5000].cpu().numpy(), po.binary_slicer_fb(x[1:]))
+
+
+@pytest.mark.parametrize("n", [8191, 8192, 8193, 16383, 16384, 16385, 40_000])
+def test_host_entries_across_the_pinned_staging_sizes(gpu, po, n):
+    """host-buffer work() calls whose transfers sit on either side of the pinned slots (32 KB) and of the hand-over to the
+    runtime's own staging (64 KB): one slot, two slots, runtime path -- same results, call after call on one handle"""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n).astype(np.float32)              # 4 n bytes in, n bytes out
+    bs = gpu.binary_slicer_fb()
+    for _ in range(3):
+        assert np.array_equal(bs.work(n, x), po.binary_slicer_fb(x))
+        x = np.roll(x, 17)
+    c = (rng.standard_normal(n + 1) + 1j * rng.standard_normal(n + 1)).astype(np.complex64)    # 8 (n + 1) bytes in, 4 n out
+    qd = gpu.quadrature_demod_cf(1.5)
+    ref = po.quad_demod_cf(1.5, c, n)
+    for _ in range(2):
+        assert np.array_equal(qd.work(n, c).view(np.uint32), ref.view(np.uint32))
