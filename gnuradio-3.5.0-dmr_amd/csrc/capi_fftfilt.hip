@@ -140,9 +140,9 @@ int grhip_fft_filter_ccc_work_device(grhip_fft_filter_ccc *h, int noutput_items,
         const float2 *hist = h->d_hist[h->hist_cur].as<float2>();
         float2 *hist_new = h->d_hist[h->hist_cur ^ 1].as<float2>();
         if ((rc = launch_fftfilt4096((const float2 *)d_in, nin, hist, h->ntaps, h->d_tw4096.as<float2>(),
-                                     h->d_H4096.as<float2>(), (float2 *)d_out, noutput_items, h->decim, h->L, h->fold, st)))
+                                     h->d_H4096.as<float2>(), (float2 *)d_out, noutput_items, h->decim, h->L, h->fold, st,
+                                     hist_new)))
             return rc;
-        if ((rc = launch_fftfilt_hist((const float2 *)d_in, nin, hist, hist_new, h->ntaps - 1, st))) return rc;
         h->hist_cur ^= 1;
         return noutput_items;
     }

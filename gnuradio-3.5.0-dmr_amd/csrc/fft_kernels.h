@@ -32,8 +32,10 @@ constexpr int OLS_N = 4096, OLS_MAX_TAPS = 2049;
 // twiddle table and transformed taps (scaled by 1/4096) for launch_fftfilt4096; taps = ntaps complex floats
 // (interleaved), h[k] multiplies x[i-k].  L = outputs per block at full rate, a multiple of `decim`.
 int ols_build(const float *taps_cplx, int ntaps, int decim, DevBuf &d_tw, DevBuf &d_H, int *L, int *fold);
+// hist_new (optional): receives the last ntaps-1 items of (hist ++ in), the history of the next call
 int launch_fftfilt4096(const float2 *in, long long nin, const float2 *hist, int ntaps, const float2 *twiddle,
-                       const float2 *H, float2 *out, long long nout, int decim, int L, int fold, hipStream_t st);
+                       const float2 *H, float2 *out, long long nout, int decim, int L, int fold, hipStream_t st,
+                       float2 *hist_new = nullptr);
 int launch_fftfilt4096_real(const float *in, long long nin, const float *hist, int ntaps, const float2 *twiddle,
                             const float2 *H, float *out, long long nout, int decim, int L, int fold, hipStream_t st);
 int launch_fftfilt_hist(const float2 *in, long long nin, const float2 *hist_old, float2 *hist_new, int hlen, hipStream_t st);

@@ -799,13 +799,23 @@ template <bool REAL, int FOLD>
 __global__ void __launch_bounds__(256, 3)
 fftfilt4096_kernel(const void *__restrict__ in_v, long long nin, const void *__restrict__ hist_v, int ntaps,
                    const float2 *__restrict__ twiddle, const float2 *__restrict__ H, void *__restrict__ out_v,
-                   long long nout, int decim, int L, long long nblk)
+                   long long nout, int decim, int L, long long nblk, void *__restrict__ hist_new_v)
 {
     constexpr int N = 4096;
     __shared__ f32x2_t S[N + N / 16];
     __shared__ f32x2_t W2[16 * 17];
     typedef unsigned int ols_u32x2 __attribute__((ext_vector_type(2)));
     const int t = threadIdx.x;
+    // the history of the NEXT call (the last ntaps - 1 items of history ++ stream; its own buffer, the caller flips the
+    // two): the last workgroup writes it on its way in (a kernel of its own cost 5 us per call)
+    if (hist_new_v && blockIdx.x == gridDim.x - 1) {
+        const int hlen = ntaps - 1;
+        for (int j = t; j < hlen; j += 256) {
+            const long long i = nin - hlen + j;          // index into the stream, negative: still in the old history
+            if (REAL) ((float *)hist_new_v)[j] = i >= 0 ? ((const float *)in_v)[i] : ((const float *)hist_v)[i + hlen];
+            else ((float2 *)hist_new_v)[j] = i >= 0 ? ((const float2 *)in_v)[i] : ((const float2 *)hist_v)[i + hlen];
+        }
+    }
     f32x2_t w3[16];
 #pragma unroll
     for (int q = 1; q < 16; ++q) { const float2 w = twiddle[t * q]; w3[q] = f32x2_t{w.x, w.y}; }
@@ -1012,39 +1022,70 @@ int ols_build(const float *taps_cplx, int ntaps, int decim, DevBuf &d_tw, DevBuf
     return GRHIP_OK;
 }
 
+static int launch_fftfilt_hist_any(bool real, const void *in, long long nin, const void *hist_old, void *hist_new, int hlen, hipStream_t st);
+
 template <bool REAL>
 static int launch_fftfilt4096_t(const void *in, long long nin, const void *hist, int ntaps, const float2 *twiddle,
-                                const float2 *H, void *out, long long nout, int decim, int L, int fold, hipStream_t st)
+                                const float2 *H, void *out, long long nout, int decim, int L, int fold, hipStream_t st,
+                                void *hist_new)
 {
     if (nout <= 0) return GRHIP_OK;
-    const long long nblk = (nin + L - 1) / L;
-    if (nin * (REAL ? 4 : 8) > 0x7fffffffLL) return fail(GRHIP_EINVAL, "overlap-save engine: more than 2 GB of input in one call");
+    // The kernel addresses a launch's input and output through 32-bit byte offsets: a longer call goes out in pieces of
+    // whole blocks (blocks are independent: the history of a later piece is the stream itself).
+    constexpr long long ISZ = REAL ? 4 : 8;
+    const long long max_blocks = (0x7fff0000LL / ISZ - 2 * OLS_N) / L;
+    const long long nblk_all = (nin + L - 1) / L;
     const long long cap = 3LL * fft_num_cus();
-    const unsigned grid = (unsigned)(nblk < cap ? nblk : cap);
-#define GRHIP_OLS_LAUNCH(F) hipLaunchKernelGGL((fftfilt4096_kernel<REAL, F>), dim3(grid), dim3(256), 0, st, in, nin, hist, ntaps, \
-                                               twiddle, H, out, nout, decim, L, nblk)
-    switch (fold) {
-    case 1: GRHIP_OLS_LAUNCH(1); break;
-    case 2: GRHIP_OLS_LAUNCH(2); break;
-    case 3: GRHIP_OLS_LAUNCH(3); break;
-    case 4: GRHIP_OLS_LAUNCH(4); break;
-    default: GRHIP_OLS_LAUNCH(0); break;
-    }
+    for (long long b0 = 0; b0 < nblk_all; b0 += max_blocks) {
+        const long long nb = nblk_all - b0 < max_blocks ? nblk_all - b0 : max_blocks;
+        const long long i0 = b0 * L, o0 = b0 * (L / decim);
+        const void *in_c = (const char *)in + i0 * ISZ;
+        const void *hist_c = b0 == 0 ? hist : (const void *)((const char *)in_c - (long long)(ntaps - 1) * ISZ);
+        void *out_c = (char *)out + o0 * ISZ;
+        const bool last = b0 + nb >= nblk_all;
+        // (a piece in the middle reads on into the next one: its last block needs up to 4096 items from its start)
+        const long long nin_rd = last || nin - i0 < nb * (long long)L + OLS_N ? nin - i0 : nb * (long long)L + OLS_N;
+        const long long nout_c = last ? nout - o0 : nb * (L / decim);
+        const unsigned grid = (unsigned)(nb < cap ? nb : cap);
+        void *hn = last ? hist_new : nullptr;
+        if (hn && b0 != 0) {
+            // the next call's history is defined against the whole call: written by a piece only when the piece is the call
+            const int rc = launch_fftfilt_hist_any(REAL, in, nin, hist, hn, ntaps - 1, st);
+            if (rc) return rc;
+            hn = nullptr;
+        }
+#define GRHIP_OLS_LAUNCH(F) hipLaunchKernelGGL((fftfilt4096_kernel<REAL, F>), dim3(grid), dim3(256), 0, st, in_c, nin_rd, hist_c, ntaps, \
+                                               twiddle, H, out_c, nout_c, decim, L, nb, hn)
+        switch (fold) {
+        case 1: GRHIP_OLS_LAUNCH(1); break;
+        case 2: GRHIP_OLS_LAUNCH(2); break;
+        case 3: GRHIP_OLS_LAUNCH(3); break;
+        case 4: GRHIP_OLS_LAUNCH(4); break;
+        default: GRHIP_OLS_LAUNCH(0); break;
+        }
 #undef GRHIP_OLS_LAUNCH
-    GRHIP_HIP(hipGetLastError());
+        GRHIP_HIP(hipGetLastError());
+    }
     return GRHIP_OK;
 }
 
 int launch_fftfilt4096(const float2 *in, long long nin, const float2 *hist, int ntaps, const float2 *twiddle,
-                       const float2 *H, float2 *out, long long nout, int decim, int L, int fold, hipStream_t st)
+                       const float2 *H, float2 *out, long long nout, int decim, int L, int fold, hipStream_t st,
+                       float2 *hist_new)
 {
-    return launch_fftfilt4096_t<false>(in, nin, hist, ntaps, twiddle, H, out, nout, decim, L, fold, st);
+    return launch_fftfilt4096_t<false>(in, nin, hist, ntaps, twiddle, H, out, nout, decim, L, fold, st, hist_new);
 }
 
 int launch_fftfilt4096_real(const float *in, long long nin, const float *hist, int ntaps, const float2 *twiddle,
                             const float2 *H, float *out, long long nout, int decim, int L, int fold, hipStream_t st)
 {
-    return launch_fftfilt4096_t<true>(in, nin, hist, ntaps, twiddle, H, out, nout, decim, L, fold, st);
+    return launch_fftfilt4096_t<true>(in, nin, hist, ntaps, twiddle, H, out, nout, decim, L, fold, st, nullptr);
+}
+
+static int launch_fftfilt_hist_any(bool real, const void *in, long long nin, const void *hist_old, void *hist_new, int hlen, hipStream_t st)
+{
+    if (real) return fail(GRHIP_EINVAL, "overlap-save engine: no history buffer for real data");
+    return launch_fftfilt_hist((const float2 *)in, nin, (const float2 *)hist_old, (float2 *)hist_new, hlen, st);
 }
 
 int launch_fftfilt_hist(const float2 *in, long long nin, const float2 *hist_old, float2 *hist_new, int hlen, hipStream_t st)

@@ -94,6 +94,36 @@ def test_overlap_save_engine_persistent_walk(gpu, po, kind, ntaps, decim, n):
     assert err.max() <= TOL * np.abs(ref).max(), (int(err.argmax()), float(err.max()), float(np.abs(ref).max()))
 
 
+def test_overlap_save_engine_call_longer_than_2GB(gpu, po):
+    """one device call of 2.15 GB of input: the engine addresses a launch through 32-bit byte offsets, so the call goes out
+    in two pieces of whole blocks; outputs around the seam, at the very start and at the very end against the direct form"""
+    import torch
+    ntaps, L = 64, 4096 - 63
+    seam = ((0x7fff0000 // 8 - 2 * 4096) // L) * L               # first output of the second piece
+    n = seam + 3 * L + 77
+    nin = n + ntaps - 1
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    d_x = torch.empty((nin, 2), dtype=torch.float32, device=dev)
+    d_x.uniform_(-1, 1, generator=gen)
+    d_y = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+    taps = np.random.default_rng(6).uniform(-1, 1, ntaps).astype(np.float32)
+    blk = gpu.fir_filter_ccf(1, taps)
+    blk.set_mode(gpu.MODE_FAST_VALU)                            # (64 taps at decimation 1: the overlap-save engine)
+    assert blk.work_device(n, d_x, d_y, st) == n
+    st.synchronize()
+    for a in (0, seam - 5000, n - 5000):
+        m = 5000 if a + 5000 <= n else n - a
+        xs = d_x[a:a + m + ntaps - 1].cpu().numpy().reshape(-1).view(np.complex64)
+        ref = po.fir_ccf(taps, xs, m, 1)
+        got = d_y[a:a + m].cpu().numpy().reshape(-1).view(np.complex64)
+        assert np.abs(got - ref).max() <= TOL * np.abs(ref).max(), (a, float(np.abs(got - ref).max()))
+    del d_x, d_y
+    torch.cuda.empty_cache()
+
+
 def test_fir_integer_data_exact_all_modes(gpu, po):
     """integer-valued data: every summation order is exact
     (filter/qa_gr_fir_ccf.cc:103-159 uses the same trick)"""
