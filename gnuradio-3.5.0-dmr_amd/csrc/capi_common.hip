@@ -85,6 +85,10 @@ void HandleBase::pin_release(PinRing &r)
 int HandleBase::h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t st)
 {
     if (!bytes) return GRHIP_OK;
+    // mapped staging: the CPU writes the buffer the kernels are about to read (nothing of an earlier call is in flight:
+    // every host-buffer entry ends with a synchronisation)
+    for (StageBuf *b : {&stage_in, &stage_out})
+        if (void *hp = b->host_of(dst_dev)) { memcpy(hp, src_host, bytes); return GRHIP_OK; }
     if (bytes > PIN_MAX) {
         GRHIP_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
         return GRHIP_OK;
@@ -108,6 +112,12 @@ int HandleBase::h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream
 int HandleBase::d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t st)
 {
     if (!bytes) return GRHIP_OK;
+    for (StageBuf *b : {&stage_in, &stage_out})
+        if (void *hp = b->host_of(src_dev)) {      // mapped staging: the kernels wrote host memory; wait for them, copy out
+            GRHIP_HIP(hipStreamSynchronize(st));
+            memcpy(dst_host, hp, bytes);
+            return GRHIP_OK;
+        }
     if (bytes > PIN_MAX) {
         GRHIP_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
         return GRHIP_OK;

@@ -50,6 +50,44 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// Staging buffer of the host-buffer entry points.  Scheduler-sized calls (<= MAPPED_MAX bytes) get host memory that is
+// pinned AND mapped into the device's address space: the caller's items are copied into it by the CPU, the kernels read
+// and write it in place over the host link, and no copy engine is involved (a 32 KB call spent more time submitting its
+// two DMA transfers than moving them: 45 -> 26 us per 1024-output call of the fused block, 61 -> 34 at 8192;
+// tools/bench_small_calls.py).  Once a call needs more than MAPPED_MAX, the buffer becomes device memory for good.
+struct StageBuf : DevBuf {
+#ifndef GRHIP_MAPPED_MAX
+#define GRHIP_MAPPED_MAX (2 * 1024 * 1024)
+#endif
+    static constexpr size_t MAPPED_MAX = GRHIP_MAPPED_MAX;
+    void *host = nullptr;       // host address of a mapped buffer (p is its device address); null: device memory
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return GRHIP_OK;
+        if (bytes <= MAPPED_MAX && (cap == 0 || host)) {
+            size_t want = 64 * 1024;
+            while (want < bytes) want *= 2;
+            release();
+            GRHIP_HIP(hipHostMalloc(&host, want, hipHostMallocMapped));
+            if (hipHostGetDevicePointer(&p, host, 0) != hipSuccess) { (void)hipHostFree(host); host = nullptr; p = nullptr; }
+            else { cap = want; return GRHIP_OK; }
+        }
+        release();
+        return DevBuf::reserve(bytes);
+    }
+    void release()
+    {
+        if (host) { (void)hipHostFree(host); host = nullptr; p = nullptr; cap = 0; }
+        else DevBuf::release();
+    }
+    // host address of a device address inside a mapped buffer, or null
+    void *host_of(const void *dev) const
+    {
+        if (!host || (const char *)dev < (const char *)p || (const char *)dev >= (const char *)p + cap) return nullptr;
+        return (char *)host + ((const char *)dev - (const char *)p);
+    }
+};
+
 // the two counters of the tiled kernel's tile queue: zeroed once, re-armed by every launch
 struct SchedBuf {
     DevBuf b;
@@ -72,7 +110,7 @@ struct HandleBase {
     int device = 0;
     hipStream_t own_stream = nullptr;
     std::mutex setter_mutex;   // setters vs. the work thread
-    DevBuf stage_in, stage_out;
+    StageBuf stage_in, stage_out;
     // Pinned staging of the host-buffer entry points (SURVEY 8b "Ownership": the handle owns it, the caller owns its I/O
     // buffers).  Scheduler-sized transfers (<= PIN_MAX) go caller buffer -> pinned slot -> DMA and back: no page pinning or
     // runtime staging per call; two slots per direction, so a call split in chunks copies one while the other is in flight.
