@@ -67,13 +67,14 @@ static bool hidec_wanted(int decim, int ntaps, bool ctaps, bool have_ols)
     if (knob == 3) return true;
 #endif
     if (!have_ols) return true;
-    // work per input sample in units the measurements line up on (tools/bench_decim.py): taps per polyphase
-    // component, twice for complex taps, over the share of lanes a tile keeps busy
-    const int tn = hidec_outputs_per_tile(decim, ntaps);
-    const double cost = (double)ntaps / decim * (ctaps ? 2.0 : 1.0) * 512.0 / (tn < 512 ? tn : 512);
-    // round 2 (profiles/r02_decim_engines.log): the engine is 2.3x faster than in round 1, fastest where its inverse
-    // folds (decimation 8, 16)
-    return cost <= ((decim == 8 || decim == 16) ? 24.0 : 42.0);
+    // MACs per input sample (complex taps count twice) against what the engine delivers for the shape
+    // (profiles/r02_decim_engines.log, round 2's kernels on both sides): the direct kernel runs at roughly 400 Gsamples/s
+    // at 8 MACs, 320-400 at 20, 250 at 40, 130-200 at 80; the engine at 330-400 where its inverse folds (decimation 8, 16),
+    // 210-250 elsewhere up to ~500 taps, less for longer filters.
+    const double w = (double)ntaps / decim * (ctaps ? 2.0 : 1.0);
+    if (decim == 8 || decim == 16) return w <= 16.0;
+    if (w <= 32.0) return true;
+    return w <= 48.0 && ntaps <= 512 && decim >= 5;
 }
 
 // Taps per polyphase component above which the overlap-save engine takes over from the tiled vector kernel (single-stream

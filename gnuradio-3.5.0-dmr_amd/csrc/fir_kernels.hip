@@ -264,7 +264,8 @@ int launch_quad_demod(const float2 *in, float *out, long long n_out, float gain,
 //  * taps are wave-uniform scalar loads; 3 workgroups per CU cover each other's staging.
 // Optional rotator-table multiply (freq_xlating) with the reference's unfused product.
 // ===========================================================================
-constexpr int HIDEC_LDS_SAMPLES = 6400;           // 50 KB: three workgroups per CU
+constexpr int HIDEC_LDS_SAMPLES = 6144;           // 48 KB of samples + the taps: three workgroups per CU
+constexpr int HIDEC_NR = HIDEC_LDS_SAMPLES / 256 + 1;        // staging rounds of a 256-lane workgroup (upper bound)
 
 __host__ __device__ inline int hidec_sub_log(int D)
 {
@@ -273,110 +274,179 @@ __host__ __device__ inline int hidec_sub_log(int D)
     return v + 1;                                  // sub-arrays: 2P
 }
 
+// Outputs per tile: every lane computes two adjacent outputs, and all 256 lanes work -- G lane groups of 256 / G lanes
+// split the tap range between them (partial sums meet in LDS) -- so a tile is 2 * (256 / G) outputs, G the smallest
+// count whose tile fits the LDS.
+static int hidec_groups(int D, int ntaps)
+{
+    const int tn_max = (HIDEC_LDS_SAMPLES - ntaps - 64) / D;
+    for (int G = 1; G <= 8; ++G)
+        if (2 * (256 / G) <= tn_max) return G;
+    return 0;
+}
+
 int hidec_outputs_per_tile(int D, int ntaps)
 {
-    int tn = (HIDEC_LDS_SAMPLES - ntaps) / D;
-    if (tn > 512) tn = 512;
-    return tn & ~1;
+    const int G = hidec_groups(D, ntaps);
+    return G ? 2 * (256 / G) : 0;
 }
 
 bool hidec_supported(int D, int ntaps)
 {
-    return D >= 3 && D <= 256 && ntaps >= 1 && ntaps <= 2048 && hidec_outputs_per_tile(D, ntaps) >= 128;
+    return D >= 3 && D <= 256 && ntaps >= 1 && ntaps <= 2048 && hidec_groups(D, ntaps) > 0;
 }
 
 // PREMIX (freq_xlating with a real prototype): y_bp[n0+m] = e^{-jw m D} sum_k proto[k] (x[u0+u] e^{jwu}), u = mD + k
 // relative to the tile: the samples are mixed with etab[u] = e^{jwu} while they are staged, the taps are the
 // real prototype (half the FMAs), and the lane's outputs are turned back with vtab[m] = e^{-jw m D}.
+// Round 2: persistent workgroups walk the tiles with the next tile's samples (and rotator phases) requested one tile
+// ahead into registers through a range-checked buffer descriptor; the pre-mix phasors of a lane's samples are tile
+// independent and stay in registers; the taps sit in LDS (uniform-address reads: in-order with the sample reads, so the
+// waits are counted -- as scalar loads they shared a counter that can only be waited to zero); all 256 lanes compute.
 template <bool CTAPS, int V1, bool PREMIX>
 __global__ void __launch_bounds__(256, 3)
 fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__restrict__ taps_g, int ntaps, int D,
-                 int Tn, long long n_out, float2 *__restrict__ y, const float2 *__restrict__ gtab,
-                 const float2 *__restrict__ etab, const float2 *__restrict__ vtab)
+                 int G, long long n_out, float2 *__restrict__ y, const float2 *__restrict__ gtab,
+                 const float2 *__restrict__ etab, const float2 *__restrict__ vtab, long long ntiles)
 {
-    __shared__ float2 xs[HIDEC_LDS_SAMPLES + 128];             // 2P sub-arrays of odd stride: at most S + 3*2P slots
-    typedef const float __attribute__((address_space(4))) *cfp;
-    const cfp taps = (cfp)taps_g;
-    const int t = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hidec_smem[];
+    typedef float hd_f32x2 __attribute__((ext_vector_type(2)));
+    typedef float hd_f32x4 __attribute__((ext_vector_type(4)));
     constexpr int NSUB = 1 << V1, PM = NSUB - 1, SUB = ((HIDEC_LDS_SAMPLES >> V1) + 2) | 1;
-    const long long n0 = (long long)blockIdx.x * Tn;             // first output of the tile
-    const long long u0 = n0 * D;                                 // its first sample
-    const int ns = (Tn - 1) * D + ntaps + NSUB;                  // samples touched, the last tap group rounded up (all staged:
-                                                                 // a zero tap times LDS garbage could be a NaN)
-    const long long last = n_in - 1;                             // n_in >= 1 (launcher)
-    for (int ub = t; ub < ns; ub += 256 * 8) {                   // eight independent loads in flight per lane
-        float2 v[8];
+    constexpr int TW = CTAPS ? 2 : 1;
+    hd_f32x2 *xs = reinterpret_cast<hd_f32x2 *>(hidec_smem);                       // 2P sub-arrays of odd stride
+    float *tl = reinterpret_cast<float *>(hidec_smem + (size_t)(NSUB * SUB) * 8);  // the padded taps: c[k] at tl[TW (D + k)]
+    const int t = threadIdx.x;
+    const int LG = 256 / G;                          // lanes per group
+    const int grp = t / LG, tp = t - grp * LG;       // tap group, output pair inside the tile
+    const bool idle = grp >= G;                      // (256 - G * LG lanes when G does not divide 256)
+    const int Tn = 2 * LG;
+    const int ns = (Tn - 1) * D + ntaps + NSUB;      // samples touched, the last tap group rounded up (all staged)
+    const int ntl = (ntaps + 2 * D + 64) * TW;
+    for (int i = t; i < ntl; i += 256) tl[i] = taps_g[i];
+
+    // per-lane constants of the staging rounds: u = t + 256 i -> sub-array t & PM, index (t >> V1) + (256 >> V1) i
+    const int st_slot = (t & PM) * SUB + (t >> V1);
+    constexpr int ST_STEP = 256 >> V1;
+    hd_f32x2 ph[PREMIX ? HIDEC_NR : 1];
+    if (PREMIX) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long long g = u0 + ub + 256 * j;
-            v[j] = x[g < last ? g : last];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int u = ub + 256 * j;
-            if (u < ns) {
-                float2 w = u0 + u < n_in ? v[j] : make_float2(0.f, 0.f);
-                if (PREMIX) w = cmul_ref(w, etab[u]);
-                xs[(u & PM) * SUB + (u >> V1)] = w;
-            }
+        for (int i = 0; i < HIDEC_NR; ++i) {
+            const int u = t + 256 * i;
+            const float2 e = etab[u < HIDEC_LDS_SAMPLES + 128 ? u : 0];
+            ph[i] = hd_f32x2{e.x, e.y};
         }
     }
-    __syncthreads();
-    if (2 * t >= Tn) return;
-    const float2 *xl = xs + ((2 * t * D) >> V1);                 // 2tD is a multiple of 2P
-    float2 a0 = make_float2(0.f, 0.f), a1 = a0;
-    auto mac = [&](float2 &acc, int k, float2 xv) {
-        if (CTAPS) {
-            const float hr = taps[2 * k], hi = taps[2 * k + 1];
-            acc.x = __builtin_fmaf(hr, xv.x, acc.x);
-            acc.x = __builtin_fmaf(-hi, xv.y, acc.x);
-            acc.y = __builtin_fmaf(hr, xv.y, acc.y);
-            acc.y = __builtin_fmaf(hi, xv.x, acc.y);
-        } else {
-            const float h = taps[k];
-            acc.x = __builtin_fmaf(h, xv.x, acc.x);
-            acc.y = __builtin_fmaf(h, xv.y, acc.y);
+    hd_f32x2 v0c{1.f, 0.f}, v1c{1.f, 0.f};
+    if (PREMIX) {
+        const float2 a = vtab[2 * tp], b = vtab[2 * tp + 1];
+        v0c = hd_f32x2{a.x, a.y}; v1c = hd_f32x2{b.x, b.y};
+    }
+    // the stream: items >= n_in read as zero (and move no bytes)
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x), 0, (int)(n_in * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(gtab), 0, gtab ? (int)(n_out * 8) : 0, 0x00020000);
+    hd_f32x2 pre[HIDEC_NR];
+    hd_f32x4 gq{1.f, 0.f, 1.f, 0.f};
+    auto request = [&](long long tile) __attribute__((always_inline)) {
+        int tq = t;
+        asm volatile("" : "+v"(tq));                 // (offsets per tile: hoisted, they would be spilled)
+        const long long u0 = tile * Tn * D;
+        const int vo = (int)(u0 * 8) + 8 * tq;
+#pragma unroll
+        for (int i = 0; i < HIDEC_NR; ++i) {
+            if (256 * i < ns) {                      // (wave-uniform: rounds past the tile are skipped, not loaded out of range)
+                const int off = (tq + 256 * i < ns) ? vo + 2048 * i : 0x7ffffff0;
+                pre[i] = __builtin_bit_cast(hd_f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
+            }
+        }
+        if (gtab) {
+            const long long n = tile * Tn + 2 * tp;
+            // (two 8-byte loads: an odd n_out ends in the middle of the pair)
+            const hd_f32x2 g0 = __builtin_bit_cast(hd_f32x2, __builtin_amdgcn_raw_buffer_load_b64(gr, (int)(n * 8), 0, 0));
+            const hd_f32x2 g1 = __builtin_bit_cast(hd_f32x2, __builtin_amdgcn_raw_buffer_load_b64(gr, (int)(n * 8) + 8, 0, 0));
+            gq = hd_f32x4{g0.x, g0.y, g1.x, g1.y};
         }
     };
-    // k runs over [0, ntaps + D) in groups of 2P: inside a group the sub-array is a compile-time constant, so the
-    // LDS offsets are immediates.  Tap c[k] feeds the first output (k < ntaps), c[k-D] the second (k >= D):
-    // the tap table is zero padded by D in front and behind (host), so no conditions are needed.
-    const cfp t0 = taps + (CTAPS ? 2 : 1) * D;                   // c[k] at t0[k], zeros for -D <= k < 0 and ntaps <= k < ntaps + D
+    long long tile = blockIdx.x;
+    if (tile < ntiles) request(tile);
+    __syncthreads();                                 // taps visible
+
+    // tap range of this lane's group: groups of NSUB taps, k over [0, ntaps + D)
     const int ngroups = (ntaps + D + NSUB - 1) >> V1;
-    for (int gk = 0; gk < ngroups; ++gk) {
-        const float2 *xg = xl + gk;
+    const int gper = (ngroups + G - 1) / G;
+    const int gk0 = grp * gper, gk1 = idle ? gk0 : (gk0 + gper < ngroups ? gk0 + gper : ngroups);
+    const hd_f32x2 *xl = xs + ((2 * tp * D) >> V1);  // 2 tp D is a multiple of 2P
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        // ---- registers -> LDS (pre-mixed)
 #pragma unroll
-        for (int j = 0; j < NSUB; ++j) {
-            const int k = (gk << V1) + j;
-            const float2 xv = xg[j * SUB];
-            if (CTAPS) {
-                const float hr0 = t0[2 * k], hi0 = t0[2 * k + 1], hr1 = t0[2 * (k - D)], hi1 = t0[2 * (k - D) + 1];
-                a0.x = __builtin_fmaf(hr0, xv.x, a0.x); a0.x = __builtin_fmaf(-hi0, xv.y, a0.x);
-                a0.y = __builtin_fmaf(hr0, xv.y, a0.y); a0.y = __builtin_fmaf(hi0, xv.x, a0.y);
-                a1.x = __builtin_fmaf(hr1, xv.x, a1.x); a1.x = __builtin_fmaf(-hi1, xv.y, a1.x);
-                a1.y = __builtin_fmaf(hr1, xv.y, a1.y); a1.y = __builtin_fmaf(hi1, xv.x, a1.y);
-            } else {
-                const float h0 = t0[k], h1 = t0[k - D];
-                a0.x = __builtin_fmaf(h0, xv.x, a0.x); a0.y = __builtin_fmaf(h0, xv.y, a0.y);
-                a1.x = __builtin_fmaf(h1, xv.x, a1.x); a1.y = __builtin_fmaf(h1, xv.y, a1.y);
+        for (int i = 0; i < HIDEC_NR; ++i) {
+            if (256 * i >= ns) break;
+            if (t + 256 * i < ns) {
+                hd_f32x2 w = pre[i];
+                if (PREMIX) { const float2 m = cmul_ref(make_float2(w.x, w.y), make_float2(ph[i].x, ph[i].y)); w = hd_f32x2{m.x, m.y}; }
+                xs[st_slot + ST_STEP * i] = w;
             }
         }
-    }
-    (void)mac;
-    const long long n = n0 + 2 * t;
-    if (PREMIX) {
-        a0 = cmul_ref(a0, vtab[2 * t]);
-        a1 = cmul_ref(a1, vtab[2 * t + 1]);
-    }
-    if (gtab) {
-        if (n < n_out) a0 = cmul_ref(a0, gtab[n]);
-        if (n + 1 < n_out) a1 = cmul_ref(a1, gtab[n + 1]);
-    }
-    if (n + 1 < n_out && ((((uintptr_t)(y + n)) & 15) == 0)) {
-        *reinterpret_cast<float4 *>(y + n) = make_float4(a0.x, a0.y, a1.x, a1.y);
-    } else {
-        if (n < n_out) y[n] = a0;
-        if (n + 1 < n_out) y[n + 1] = a1;
+        const hd_f32x4 gcur = gq;
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) request(tile + gridDim.x);
+
+        // ---- MACs: tap c[k] feeds the first output (k < ntaps), c[k-D] the second (k >= D); the tap table is zero padded
+        // by D in front and behind (host), so no conditions are needed
+        float a0x = 0.f, a0y = 0.f, a1x = 0.f, a1y = 0.f;
+        const float *t0 = tl + TW * D;               // c[k] at t0[TW k]
+        for (int gk = gk0; gk < gk1; ++gk) {
+            const hd_f32x2 *xg = xl + gk;
+            const int k = gk << V1;
+#pragma unroll 8
+            for (int j = 0; j < NSUB; ++j) {         // (8 at a time: 16 or 32 reads hoisted at once cost more registers than there are)
+                const hd_f32x2 xv = xg[j * SUB];
+                if (CTAPS) {
+                    const float hr0 = t0[2 * (k + j)], hi0 = t0[2 * (k + j) + 1], hr1 = t0[2 * (k + j - D)], hi1 = t0[2 * (k + j - D) + 1];
+                    a0x = __builtin_fmaf(hr0, xv.x, a0x); a0x = __builtin_fmaf(-hi0, xv.y, a0x);
+                    a0y = __builtin_fmaf(hr0, xv.y, a0y); a0y = __builtin_fmaf(hi0, xv.x, a0y);
+                    a1x = __builtin_fmaf(hr1, xv.x, a1x); a1x = __builtin_fmaf(-hi1, xv.y, a1x);
+                    a1y = __builtin_fmaf(hr1, xv.y, a1y); a1y = __builtin_fmaf(hi1, xv.x, a1y);
+                } else {
+                    const float h0 = t0[k + j], h1 = t0[k + j - D];
+                    a0x = __builtin_fmaf(h0, xv.x, a0x); a0y = __builtin_fmaf(h0, xv.y, a0y);
+                    a1x = __builtin_fmaf(h1, xv.x, a1x); a1y = __builtin_fmaf(h1, xv.y, a1y);
+                }
+            }
+        }
+        // ---- the groups' partial sums meet in LDS (the sample area is free once every lane is through its MACs)
+        if (G > 1) {
+            __syncthreads();
+            hd_f32x4 *red = reinterpret_cast<hd_f32x4 *>(xs);
+            if (grp > 0 && !idle) red[(grp - 1) * LG + tp] = hd_f32x4{a0x, a0y, a1x, a1y};
+            __syncthreads();
+            if (grp == 0) {
+                for (int g2 = 1; g2 < G; ++g2) {
+                    const hd_f32x4 r = red[(g2 - 1) * LG + tp];
+                    a0x += r[0]; a0y += r[1]; a1x += r[2]; a1y += r[3];
+                }
+            }
+        }
+        if (grp == 0) {
+            const long long n = tile * Tn + 2 * tp;
+            float2 a0 = make_float2(a0x, a0y), a1 = make_float2(a1x, a1y);
+            if (PREMIX) {
+                a0 = cmul_ref(a0, make_float2(v0c.x, v0c.y));
+                a1 = cmul_ref(a1, make_float2(v1c.x, v1c.y));
+            }
+            if (gtab) {
+                a0 = cmul_ref(a0, make_float2(gcur[0], gcur[1]));
+                a1 = cmul_ref(a1, make_float2(gcur[2], gcur[3]));
+            }
+            if (n + 1 < n_out && ((((uintptr_t)(y + n)) & 15) == 0)) {
+                *reinterpret_cast<float4 *>(y + n) = make_float4(a0.x, a0.y, a1.x, a1.y);
+            } else {
+                if (n < n_out) y[n] = a0;
+                if (n + 1 < n_out) y[n + 1] = a1;
+            }
+        }
+        __syncthreads();                             // the sample area belongs to the next tile from here
     }
 }
 
@@ -387,12 +457,33 @@ int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim,
     if (!hidec_supported(decim, ntaps) || n_in < 1) return fail(GRHIP_EINVAL, "high-decimation FIR: unsupported shape");
     const bool premix = etab && vtab;
     if (premix && ctaps) return fail(GRHIP_EINVAL, "high-decimation FIR: pre-mix form takes real taps");
-    const int Tn = hidec_outputs_per_tile(decim, ntaps);
-    const unsigned blocks = (unsigned)((n_out + Tn - 1) / Tn);
+    if (n_in * 8 > 0x7fffffffLL || n_out * 8 > 0x7fffffffLL)
+        return fail(GRHIP_EINVAL, "high-decimation FIR: more than 2 GB of items in one call");
+    const int G = hidec_groups(decim, ntaps);
+    const int Tn = 2 * (256 / G);
+    const long long ntiles = (n_out + Tn - 1) / Tn;
     const int v1 = hidec_sub_log(decim);
+    const int nsub = 1 << v1, sub = ((HIDEC_LDS_SAMPLES >> v1) + 2) | 1;
+    const size_t lds = (size_t)nsub * sub * 8 + (size_t)(ntaps + 2 * decim + 64) * (ctaps ? 2 : 1) * 4;
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        n_cus = n > 0 ? n : 256;
+    }
+    const long long per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
+    const long long cap = per_cu * n_cus;
+    const unsigned blocks = (unsigned)(ntiles < cap ? ntiles : cap);
 #define GRHIP_HIDEC(C, V, P)                                                                                            \
-    hipLaunchKernelGGL((fir_hidec_kernel<C, V, P>), dim3(blocks), dim3(256), 0, st, x, n_in, taps_padded, ntaps, decim, \
-                       Tn, n_out, y, gtab, etab, vtab)
+    do {                                                                                                                \
+        static size_t cfg = 0;                                                                                          \
+        if (lds > 48 * 1024 && lds > cfg) {                                                                             \
+            GRHIP_HIP(hipFuncSetAttribute((const void *)fir_hidec_kernel<C, V, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            cfg = lds;                                                                                                  \
+        }                                                                                                               \
+        hipLaunchKernelGGL((fir_hidec_kernel<C, V, P>), dim3(blocks), dim3(256), lds, st, x, n_in, taps_padded, ntaps, decim, \
+                           G, n_out, y, gtab, etab, vtab, ntiles);                                                      \
+    } while (0)
 #define GRHIP_HIDEC_V(C, P)                                                                                  \
     switch (v1) { case 1: GRHIP_HIDEC(C, 1, P); break; case 2: GRHIP_HIDEC(C, 2, P); break;                  \
                   case 3: GRHIP_HIDEC(C, 3, P); break; case 4: GRHIP_HIDEC(C, 4, P); break;                  \
