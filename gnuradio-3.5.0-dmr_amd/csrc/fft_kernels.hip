@@ -344,11 +344,15 @@ static void launch_fft4096(int shift, const float *window, const float2 *twiddle
     }
 }
 
+static int launch_fft8192(int forward, int shift, const float *window, const float2 *twiddle, const float2 *in, float2 *out,
+                         long long nvec, hipStream_t st);
+
 int launch_fft(int N, int forward, int shift, const float *window, const float2 *twiddle, const float2 *in,
                float2 *out, long long nvec, hipStream_t st)
 {
     if (nvec <= 0) return GRHIP_OK;
     if (!fft_size_supported(N)) return fail(GRHIP_EINVAL, "fft size %d not supported on device", N);
+    if (N == 8192) return launch_fft8192(forward, shift, window, twiddle, in, out, nvec, st);
     if (N == 4096) {
         if (nvec > 0x7fffffffLL) return fail(GRHIP_EINVAL, "fft: too many vectors in one call");
         if (forward) launch_fft4096<true>(shift, window, twiddle, in, out, nvec, st);
@@ -786,6 +790,92 @@ __device__ __forceinline__ void fft4096_mid_passes(f32x2_t (&v)[16], f32x2_t *S,
         for (int q = 1; q < 16; ++q) v[q] = FWD ? cmul_pk(v[q], w3[q]) : cmul_conj_pk(v[q], w3[q]);
         dft16<FWD>(v);
     }
+}
+
+// ===========================================================================
+// gr_fft_vcc, N = 8192: two interleaved 4096-point transforms (even and odd samples: decimation in time) on the
+// radix-16 register machinery above, and one radix-2 combine on the way out: X[k] = E[k] + W^k O[k],
+// X[k + 4096] = E[k] - W^k O[k].  A lane loads sample pairs (x[2j], x[2j+1]) with 16-byte loads; the even half goes through
+// its three passes, then the odd half (the same LDS buffer, 37 KB: three workgroups per CU instead of the one that the
+// 128 KB ping-pong buffers of the radix-4 kernel allowed: 0.12 of the HBM peak).  Persistent workgroups, the sub-transform
+// twiddles (table entries 2m) and the sixteen combine twiddles W^{t + 256 m} of the lane resident.
+// MODE as fft4096_kernel: bit 0 window, bit 1 shift (a shift by N/2 swaps the two output halves / is q ^ 8 on the way in).
+// ===========================================================================
+template <bool FWD, int MODE>
+__global__ void __launch_bounds__(256, (MODE & 1) ? 2 : 3)      // (the window's values in flight beside the points: two per CU)
+fft8192_kernel(const float *__restrict__ window, const float2 *__restrict__ twiddle, const float2 *__restrict__ in,
+               float2 *__restrict__ out, int nvec)
+{
+    constexpr int N = 8192, H = 4096;
+    __shared__ f32x2_t S[H + H / 16];
+    __shared__ f32x2_t W2[16 * 17];
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    constexpr bool WIN = MODE & 1, SHIFT = MODE & 2;
+    constexpr int SW_IN = (!FWD && SHIFT && !WIN) ? 8 : 0;
+    constexpr bool SWAP_OUT = FWD && SHIFT;
+    const int t = threadIdx.x;
+    f32x2_t w3[16], wc[16];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) { const float2 w = twiddle[2 * t * q]; w3[q] = f32x2_t{w.x, w.y}; }      // W_4096^{t q}, forward sign
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { const float2 w = twiddle[t + 256 * m]; wc[m] = f32x2_t{w.x, w.y}; }    // W_8192^{t + 256 m}
+    {
+        const float2 w = twiddle[2 * 16 * (t >> 4) * (t & 15)];
+        W2[(t >> 4) * 17 + (t & 15)] = f32x2_t{w.x, w.y};              // visible after the first barrier of the loop
+    }
+    for (int vec = blockIdx.x; vec < nvec; vec += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in + (long long)vec * N), 0, N * 8, 0x00020000);
+        f32x2_t ve[16], vo[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {       // samples 2j, 2j + 1, j = t + 256 (q ^ SW_IN)
+            const f32x4_t u = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xr, 16 * t, 4096 * (q ^ SW_IN), 0));
+            ve[q] = f32x2_t{u[0], u[1]};
+            vo[q] = f32x2_t{u[2], u[3]};
+        }
+        if (WIN) {
+            const float2 *wp = reinterpret_cast<const float2 *>(window);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const float2 ww = wp[t + 256 * q]; ve[q] = ve[q] * ww.x; vo[q] = vo[q] * ww.y; }
+        }
+        dft16<FWD>(ve);
+        fft4096_mid_passes<FWD>(ve, S, W2, w3, t);          // ve[m] = E[t + 256 m]
+        dft16<FWD>(vo);
+        fft4096_mid_passes<FWD>(vo, S, W2, w3, t);          // vo[m] = O[t + 256 m]
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(out + (long long)vec * N, 0, N * 8, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const f32x2_t p = FWD ? cmul_pk(vo[m], wc[m]) : cmul_conj_pk(vo[m], wc[m]);
+            const f32x2_t lo = ve[m] + p, hi = ve[m] - p;   // X[k], X[k + 4096], k = t + 256 m
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, SWAP_OUT ? hi : lo), yr, 8 * t, 2048 * m, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, SWAP_OUT ? lo : hi), yr, 8 * t + 8 * H, 2048 * m, 0);
+        }
+    }
+}
+
+template <bool FWD>
+static void launch_fft8192_t(int shift, const float *window, const float2 *twiddle, const float2 *in, float2 *out,
+                             long long nvec, hipStream_t st)
+{
+    const long long cap = (window ? 2LL : 3LL) * fft_num_cus();
+    const dim3 grid((unsigned)(nvec < cap ? nvec : cap));
+    const int nv = (int)nvec;
+    switch ((window ? 1 : 0) | (shift ? 2 : 0)) {
+    case 0: hipLaunchKernelGGL((fft8192_kernel<FWD, 0>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    case 1: hipLaunchKernelGGL((fft8192_kernel<FWD, 1>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    case 2: hipLaunchKernelGGL((fft8192_kernel<FWD, 2>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    default: hipLaunchKernelGGL((fft8192_kernel<FWD, 3>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    }
+}
+
+static int launch_fft8192(int forward, int shift, const float *window, const float2 *twiddle, const float2 *in, float2 *out,
+                          long long nvec, hipStream_t st)
+{
+    if (nvec > 0x7fffffffLL) return fail(GRHIP_EINVAL, "fft: too many vectors in one call");
+    if (forward) launch_fft8192_t<true>(shift, window, twiddle, in, out, nvec, st);
+    else launch_fft8192_t<false>(shift, window, twiddle, in, out, nvec, st);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
 }
 
 // REAL: float items in and out (gr_fir_fff shapes the tiled kernel does not take): the imaginary

@@ -44,7 +44,7 @@ def test_fft_sizes_vs_oracle(gpu, po, N, forward):
 
 @pytest.mark.parametrize("forward,shift,win", [(True, True, False), (False, True, False), (True, False, True),
                                                (False, True, True), (True, True, True)])
-@pytest.mark.parametrize("N,nvec", [(256, 7), (4096, 3)])     # 4096: the radix-16 kernel
+@pytest.mark.parametrize("N,nvec", [(256, 7), (4096, 3), (8192, 3)])     # 4096 / 8192: the radix-16 kernels
 def test_fft_window_and_shift(gpu, po, forward, shift, win, N, nvec):
     rng = np.random.default_rng(5)
     x = _rc(rng, N * nvec)
@@ -57,12 +57,12 @@ def test_fft_window_and_shift(gpu, po, forward, shift, win, N, nvec):
     assert blk.set_window(np.ones(N, np.float32)) is True
 
 
+@pytest.mark.parametrize("N,nvec", [(4096, 2100), (8192, 1700)])
 @pytest.mark.parametrize("forward,shift,win", [(True, False, False), (False, True, False), (True, True, True)])
-def test_fft4096_persistent_walk(gpu, po, forward, shift, win):
-    """more vectors than resident workgroups (4 per CU plain, 3 windowed): every workgroup walks several vectors with the
-    next one's points in flight, a ragged last round; every vector against the oracle"""
+def test_fft4096_persistent_walk(gpu, po, forward, shift, win, N, nvec):
+    """more vectors than resident workgroups (4 per CU plain, 3 windowed; 8192 points: 3 and 2): every workgroup walks
+    several vectors (4096: with the next one's points in flight), a ragged last round; every vector against the oracle"""
     rng = np.random.default_rng(11)
-    N, nvec = 4096, 2100
     x = _rc(rng, N * nvec)
     w = np.hamming(N).astype(np.float32) if win else None
     ref = po.fft_vcc(N, forward, w, shift, x)
