@@ -346,6 +346,8 @@ static void launch_fft4096(int shift, const float *window, const float2 *twiddle
 
 static int launch_fft8192(int forward, int shift, const float *window, const float2 *twiddle, const float2 *in, float2 *out,
                          long long nvec, hipStream_t st);
+static int launch_fft16x(int N, int forward, int shift, const float *window, const float2 *twiddle, const float2 *in,
+                         float2 *out, long long nvec, hipStream_t st);
 
 int launch_fft(int N, int forward, int shift, const float *window, const float2 *twiddle, const float2 *in,
                float2 *out, long long nvec, hipStream_t st)
@@ -353,6 +355,7 @@ int launch_fft(int N, int forward, int shift, const float *window, const float2 
     if (nvec <= 0) return GRHIP_OK;
     if (!fft_size_supported(N)) return fail(GRHIP_EINVAL, "fft size %d not supported on device", N);
     if (N == 8192) return launch_fft8192(forward, shift, window, twiddle, in, out, nvec, st);
+    if (N == 256 || N == 512 || N == 1024 || N == 2048) return launch_fft16x(N, forward, shift, window, twiddle, in, out, nvec, st);
     if (N == 4096) {
         if (nvec > 0x7fffffffLL) return fail(GRHIP_EINVAL, "fft: too many vectors in one call");
         if (forward) launch_fft4096<true>(shift, window, twiddle, in, out, nvec, st);
@@ -790,6 +793,194 @@ __device__ __forceinline__ void fft4096_mid_passes(f32x2_t (&v)[16], f32x2_t *S,
         for (int q = 1; q < 16; ++q) v[q] = FWD ? cmul_pk(v[q], w3[q]) : cmul_conj_pk(v[q], w3[q]);
         dft16<FWD>(v);
     }
+}
+
+// ===========================================================================
+// gr_fft_vcc, N = 256, 512, 1024, 2048: the radix-16 register kernel with N / 16 lanes per vector (a 256-lane workgroup
+// carries 4096 / N vectors at a time): two radix-16 passes and one pass of radix R3 = N / 256 (none for 256) in which a
+// lane does 16 / R3 butterflies on the sixteen points it holds.  Every pass reads point q of lane l at l + (N/16) q of its
+// vector (pass 1: straight from HBM), so the three passes share one index pattern; the last writes HBM directly.
+// Persistent workgroups, next group's points requested one group ahead, middle-pass twiddles in LDS, last-pass twiddles
+// in registers -- as fft4096_kernel.  (The radix-4 LDS kernel these sizes used before fetched three twiddles per
+// butterfly and pass from global memory: 0.27-0.50 of the HBM peak.)
+// ===========================================================================
+template <bool FWD>
+__device__ __forceinline__ void radix2(f32x2_t &a, f32x2_t &b)
+{
+    const f32x2_t s = a + b, d = a - b;
+    a = s; b = d;
+}
+
+// v[m] <- sum_n v[n] W8^{nm} (natural order in, natural order out)
+template <bool FWD>
+__device__ __forceinline__ void dft8(f32x2_t &x0, f32x2_t &x1, f32x2_t &x2, f32x2_t &x3, f32x2_t &x4, f32x2_t &x5, f32x2_t &x6, f32x2_t &x7)
+{
+    // n = n0 + 2 n1 (n0 < 2, n1 < 4): radix-4 over n1 for even and odd n, twiddle W8^{n0 k1}, radix-2 over n0
+    f32x2_t e0 = x0, e1 = x2, e2 = x4, e3 = x6, o0 = x1, o1 = x3, o2 = x5, o3 = x7;
+    radix4<FWD>(e0, e1, e2, e3);        // E[k1]
+    radix4<FWD>(o0, o1, o2, o3);        // O[k1]
+    const float H = 0.70710678118654752f, sg = FWD ? -1.f : 1.f;
+    o1 = cmul_pk(o1, f32x2_t{H, sg * H});                               // W8^1
+    o2 = FWD ? f32x2_t{o2.y, -o2.x} : f32x2_t{-o2.y, o2.x};            // W8^2 = -/+ i
+    o3 = cmul_pk(o3, f32x2_t{-H, sg * H});                              // W8^3
+    x0 = e0 + o0; x4 = e0 - o0;
+    x1 = e1 + o1; x5 = e1 - o1;
+    x2 = e2 + o2; x6 = e2 - o2;
+    x3 = e3 + o3; x7 = e3 - o3;
+}
+
+template <int N, bool FWD, int MODE>
+__global__ void __launch_bounds__(256, 3)
+fft16x_kernel(const float *__restrict__ window, const float2 *__restrict__ twiddle, const float2 *__restrict__ in,
+              float2 *__restrict__ out, int nvec)
+{
+    constexpr int LPV = N / 16;                 // lanes per vector
+    constexpr int VPG = 256 / LPV;              // vectors per workgroup step
+    constexpr int R3 = N / 256;                 // radix of the third pass (1: none)
+    constexpr int NB3 = R3 > 1 ? 16 / R3 : 0;   // its butterflies per lane
+    constexpr int VS = N + N / 16;              // LDS slots per vector (one pad slot per 16)
+    __shared__ f32x2_t S[VPG * VS];
+    __shared__ f32x2_t W2[16 * 17];
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    constexpr bool WIN = MODE & 1, SHIFT = MODE & 2;
+    constexpr int SW_IN = (!FWD && SHIFT && !WIN) ? 8 : 0;
+    constexpr bool SHIFT_OUT = FWD && SHIFT;
+    const int t = threadIdx.x;
+    const int l = t % LPV, vl = t / LPV;        // lane inside its vector, vector inside the group
+    f32x2_t *Sv = S + vl * VS;
+
+    {   // middle pass: W_256^{k q} = table[(N / 256) k q]
+        const float2 w = twiddle[(N / 256) * (t >> 4) * (t & 15)];
+        W2[(t >> 4) * 17 + (t & 15)] = f32x2_t{w.x, w.y};
+    }
+    // third pass: butterfly b of the lane is i = l + LPV b, k = i mod 256, twiddles W_N^{k m}, m = 1 .. R3 - 1 (forward sign)
+    f32x2_t w3[NB3 > 0 ? NB3 * (R3 - 1) : 1];
+    if (R3 > 1) {
+#pragma unroll
+        for (int b = 0; b < NB3; ++b)
+#pragma unroll
+            for (int m = 1; m < R3; ++m) {
+                const int k = (l + LPV * b) & 255;
+                const float2 w = twiddle[(k * m) & (N - 1)];
+                w3[b * (R3 - 1) + m - 1] = f32x2_t{w.x, w.y};
+            }
+    }
+    float wn[WIN ? 16 : 1];
+    if (WIN) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wn[q] = window[l + LPV * q];
+    }
+    const long long ngroups = ((long long)nvec + VPG - 1) / VPG;
+    f32x2_t pre[16];
+    auto request = [&](long long grp) __attribute__((always_inline)) {
+        const long long vec = grp * VPG + vl;
+        // (a whole group through one descriptor: vectors past nvec are out of its range)
+        const long long left = ((long long)nvec - grp * VPG) * (long long)(N * 8);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in + grp * VPG * (long long)N), 0,
+                                                                          (int)(left < (long long)VPG * N * 8 ? left : (long long)VPG * N * 8), 0x00020000);
+        (void)vec;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            pre[q] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, 8 * (vl * N + l), 8 * LPV * (q ^ SW_IN), 0));
+    };
+    long long grp = blockIdx.x;
+    if (grp < ngroups) request(grp);
+    for (; grp < ngroups; grp += gridDim.x) {
+        f32x2_t v[16];
+        // ---- pass 1 (p = 1)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = WIN ? pre[q] * wn[q] : pre[q];
+        dft16<FWD>(v);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) Sv[17 * l + m] = v[m];
+        __syncthreads();
+        if (grp + gridDim.x < ngroups) request(grp + gridDim.x);
+        // ---- pass 2 (p = 16)
+        {
+            const int k = l & 15;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = Sv[l + (l >> 4) + (LPV + LPV / 16) * q];
+            __syncthreads();
+#pragma unroll
+            for (int q0 = 0; q0 < 16; q0 += 2) {
+#pragma unroll
+                for (int q = q0 ? q0 : 1; q < q0 + 2; ++q) v[q] = FWD ? cmul_pk(v[q], W2[k * 17 + q]) : cmul_conj_pk(v[q], W2[k * 17 + q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            dft16<FWD>(v);
+        }
+        const long long vec = grp * VPG + vl;
+        const long long left = ((long long)nvec - grp * VPG) * (long long)(N * 8);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(out + grp * VPG * (long long)N, 0,
+                                                                           (int)(left < (long long)VPG * N * 8 ? left : (long long)VPG * N * 8), 0x00020000);
+        (void)vec;
+        const int j2 = (l - (l & 15)) * 16 + (l & 15);          // pass 2 writes element j2 + 16 m
+        if (R3 == 1) {
+            // N = 256: pass 2 is the last one; a shift by N / 2 = 128 = 16 * 8 is m ^ 8
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v[m]), yr, 8 * (vl * N + j2), 8 * 16 * (m ^ (SHIFT_OUT ? 8 : 0)), 0);
+            continue;
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) Sv[j2 + (j2 >> 4) + 17 * m] = v[m];
+        __syncthreads();
+        // ---- pass 3 (p = 256, radix R3): butterfly b works on points q = b + NB3 m
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = Sv[l + (l >> 4) + (LPV + LPV / 16) * q];
+        __syncthreads();                                        // S belongs to the next group from here
+#pragma unroll
+        for (int b = 0; b < NB3; ++b) {
+#pragma unroll
+            for (int m = 1; m < R3; ++m) {
+                f32x2_t &x = v[b + NB3 * m];
+                x = FWD ? cmul_pk(x, w3[b * (R3 - 1) + m - 1]) : cmul_conj_pk(x, w3[b * (R3 - 1) + m - 1]);
+            }
+            if (R3 == 2) radix2<FWD>(v[b], v[b + NB3]);
+            if (R3 == 4) radix4<FWD>(v[b], v[b + NB3], v[b + 2 * NB3], v[b + 3 * NB3]);
+            if (R3 == 8) dft8<FWD>(v[b], v[b + NB3], v[b + 2 * NB3], v[b + 3 * NB3], v[b + 4 * NB3], v[b + 5 * NB3], v[b + 6 * NB3], v[b + 7 * NB3]);
+            // output m of the butterfly is element j + 256 m, i = l + LPV b, k = i mod 256, j = (i - k) R3 + k
+            const int i = l + LPV * b, k = i & 255, j = (i - k) * R3 + k;
+#pragma unroll
+            for (int m = 0; m < R3; ++m)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v[b + NB3 * m]), yr, 8 * (vl * N + j),
+                                                      8 * 256 * (m ^ (SHIFT_OUT ? R3 / 2 : 0)), 0);
+        }
+    }
+}
+
+template <int N, bool FWD>
+static void launch_fft16x_t(int shift, const float *window, const float2 *twiddle, const float2 *in, float2 *out,
+                            long long nvec, hipStream_t st)
+{
+    constexpr int VPG = 4096 / N;
+    const long long ngroups = (nvec + VPG - 1) / VPG;
+    const long long cap = 3LL * fft_num_cus();
+    const dim3 grid((unsigned)(ngroups < cap ? ngroups : cap));
+    const int nv = (int)nvec;
+    switch ((window ? 1 : 0) | (shift ? 2 : 0)) {
+    case 0: hipLaunchKernelGGL((fft16x_kernel<N, FWD, 0>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    case 1: hipLaunchKernelGGL((fft16x_kernel<N, FWD, 1>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    case 2: hipLaunchKernelGGL((fft16x_kernel<N, FWD, 2>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    default: hipLaunchKernelGGL((fft16x_kernel<N, FWD, 3>), grid, dim3(256), 0, st, window, twiddle, in, out, nv); break;
+    }
+}
+
+static int launch_fft16x(int N, int forward, int shift, const float *window, const float2 *twiddle, const float2 *in,
+                         float2 *out, long long nvec, hipStream_t st)
+{
+    if (nvec > 0x7fffffffLL) return fail(GRHIP_EINVAL, "fft: too many vectors in one call");
+#define GRHIP_FFT16X(NN) do { if (forward) launch_fft16x_t<NN, true>(shift, window, twiddle, in, out, nvec, st); \
+                              else launch_fft16x_t<NN, false>(shift, window, twiddle, in, out, nvec, st); } while (0)
+    switch (N) {
+    case 256: GRHIP_FFT16X(256); break;
+    case 512: GRHIP_FFT16X(512); break;
+    case 1024: GRHIP_FFT16X(1024); break;
+    default: GRHIP_FFT16X(2048); break;
+    }
+#undef GRHIP_FFT16X
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
 }
 
 // ===========================================================================
