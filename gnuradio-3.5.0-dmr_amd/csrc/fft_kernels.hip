@@ -476,7 +476,7 @@ typedef const float __attribute__((address_space(4))) *pfb_cfloat_p;
 // per launch and stay in SGPRs, the FIR is straight-line code and the tile's 512 + 8 NT samples per stream are nine
 // 64-lane rounds of range-checked buffer loads (no branches); NT = 0 takes any length with the taps read in the loop.
 template <int M, int NT>
-__global__ void __launch_bounds__(64 * M) __attribute__((amdgpu_waves_per_eu(M == 8 ? 6 : 1)))       // (M = 8: 40 KB of LDS -> three per CU)
+__global__ void __launch_bounds__(64 * M) __attribute__((amdgpu_waves_per_eu(M == 8 && NT > 0 ? 6 : 1)))       // (M = 8, resident taps: 40 KB of LDS -> three per CU)
 pfb_os1_kernel(const PfbArgs a, long long ntiles)
 {
     constexpr int R = 8, TT = 64 * R;                  // output vectors per tile
@@ -511,45 +511,37 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
 
     // (NT > 0) the next tile's samples are requested as soon as this tile's have left their registers for LDS: HBM latency
     // runs under the FIR, the DFT and the stores
-    constexpr int NR = NT ? (TT + R * NT + 63) / 64 : 1;
+    // (NT = 0: up to 256 taps per filter -- twelve rounds, the ones past the tile skipped -- and the wave's taps in LDS
+    // behind the sample area, read at a wave-uniform address: in order with the sample reads, where scalar loads in the
+    // loop shared a counter that can only be waited to zero)
+    constexpr int NR = NT ? (TT + R * NT + 63) / 64 : 12;
     pfb_f32x2 pv[NR];
     auto request = [&](long long tile_) __attribute__((always_inline)) {
         const int vb = (int)((tile_ * TT + 1) * 8) + 8 * ln;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int m = ln + 64 * i;
-            pv[i] = __builtin_bit_cast(pfb_f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, m < tot ? vb + 512 * i : OOB, 0, 0));
+            if (NT || 64 * i < tot) {
+                const int m = ln + 64 * i;
+                pv[i] = __builtin_bit_cast(pfb_f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, m < tot ? vb + 512 * i : OOB, 0, 0));
+            }
         }
     };
-    if (NT && (long long)blockIdx.x < ntiles) request(blockIdx.x);
+    float *tlj = reinterpret_cast<float *>(smem + (size_t)M * XS * sizeof(float2)) + (size_t)j * tpfp;
+    if (!NT) {
+        for (int q = ln; q < tpfp; q += 64) tlj[q] = q < a.tpf ? taps[q] : 0.f;       // (wave-private: ordered by the first barrier)
+    }
+    if ((long long)blockIdx.x < ntiles) request(blockIdx.x);
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long t0 = tile * TT;
         // ---- stage stream j: items in_j[t0+1 .. t0+TT+tpfp]
-        const int vbase = (int)((t0 + 1) * 8) + 8 * ln;
-        if (NT) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int m = ln + 64 * i;
-                if (m < tot) dst[m + (m >> 3)] = pv[i];
-            }
-            if (tile + gridDim.x < ntiles) request(tile + gridDim.x);
-        } else {
-            // eight independent loads in flight per lane
-            for (int mb = ln; mb < tot; mb += 64 * 8) {
-                pfb_f32x2 pv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int m = mb + 64 * i;
-                    pv[i] = __builtin_bit_cast(pfb_f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, m < tot ? vbase + 8 * (mb - ln) + 512 * i : OOB, 0, 0));
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int m = mb + 64 * i;
-                    if (m < tot) dst[m + (m >> 3)] = pv[i];
-                }
-            }
+        for (int i = 0; i < NR; ++i) {
+            if (!NT && 64 * i >= tot) break;
+            const int m = ln + 64 * i;
+            if (m < tot) dst[m + (m >> 3)] = pv[i];
         }
+        if (tile + gridDim.x < ntiles) request(tile + gridDim.x);
         // (wave-private region: no workgroup barrier needed; the compiler's own waits order the LDS stores and reads of a lane,
         // the wave barrier keeps it from moving one lane's reads above another lane's stores)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -581,9 +573,10 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
             } else {
                 for (int q0 = 0; q0 < tpfp; q0 += R) {
                     const int nxt = q0 + R + (q0 >> 3) + 1;
+                    const pfb_f32x4 ha = *reinterpret_cast<const pfb_f32x4 *>(tlj + q0), hb = *reinterpret_cast<const pfb_f32x4 *>(tlj + q0 + 4);
 #pragma unroll
                     for (int qq = 0; qq < R; ++qq) {
-                        const float h = (q0 + qq < a.tpf) ? taps[q0 + qq] : 0.f;
+                        const float h = qq < 4 ? ha[qq] : hb[qq - 4];
                         const pfb_f32x2 hv = (pfb_f32x2){h, h};
 #pragma unroll
                         for (int r = 0; r < R; ++r) accv[r] = __builtin_elementwise_fma(hv, w[(qq + r) & (R - 1)], accv[r]);
@@ -699,8 +692,8 @@ static int launch_pfb_os1(const PfbArgs &a, hipStream_t st)
     const int R = 8, TT = 512;
     const int tpfp = (a.tpf + R - 1) / R * R;
     const int XS = (TT + tpfp + R) + (TT + tpfp + R) / R + 1;
-    const size_t lds = (size_t)M * XS * sizeof(float2);
-    if (lds > 150 * 1024) return -1;
+    const size_t lds = (size_t)M * XS * sizeof(float2) + (tpfp / R > 4 ? (size_t)M * tpfp * sizeof(float) : 0);
+    if (lds > 150 * 1024 || tpfp > 256) return -1;
     if ((a.nout + a.tpf) * 8 > 0xffffffffLL) return -1;         // the stream's buffer descriptor counts bytes in 32 bits
     switch (tpfp / R) {
     case 1: return launch_pfb_os1_nt<M, 1>(a, lds, st);
