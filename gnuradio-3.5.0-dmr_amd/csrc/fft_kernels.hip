@@ -704,6 +704,74 @@ static int launch_pfb_os1(const PfbArgs &a, hipStream_t st)
     }
 }
 
+// General channeliser, M <= 64: the mapping of pfb_kernel turned round.  There, neighbouring lanes were neighbouring STREAMS
+// (addresses a whole stream apart: every 8-byte load its own memory transaction; 0.05-0.10 of the HBM peak); here a wave is
+// 64 consecutive output vectors of ONE stream (consecutive addresses, the taps' window sliding through L1), ty walks the
+// streams, and the same lanes then produce the bins of their vector from LDS.  Filter part in the reference's generic
+// order, unfused (bit-exact), as before.
+__global__ void __launch_bounds__(1024)
+pfb_rows_kernel(const PfbArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *slots = (float2 *)smem;             // [64][M + 1]
+    const int M = a.M, tpf = a.tpf, MP = M + 1;
+    const int tx = threadIdx.x, ty = threadIdx.y, YS = blockDim.y;
+    const long long t = (long long)blockIdx.x * 64 + tx;
+    const bool active = t < a.nout;
+    long long c = 0, n = 0;
+    int last = 0;
+    if (active) {
+        c = (t + 1) * (long long)a.rate_ratio - 1;
+        last = (int)(c % M);
+        n = 1 + c / M;
+    }
+    for (int j = ty; j < M; j += YS) {
+        if (active) {
+            int filt; long long pos;
+            if (j <= last) { filt = last - j; pos = n; }
+            else           { filt = M + last - j; pos = n - 1; }
+            const float *__restrict__ dt = a.ftaps + (size_t)filt * tpf;
+            const float2 *__restrict__ x = a.in + (long long)j * a.stride + pos;
+            // gr_fir_ccf_generic::filter (2 complex accumulators, .cc.t:59-79)
+            float a0r = 0, a0i = 0, a1r = 0, a1i = 0;
+            int i = 0, nn = (tpf / 2) * 2;
+            for (i = 0; i < nn; i += 2) {
+                float2 v0 = x[i], v1 = x[i + 1];
+                float t0 = dt[i], t1 = dt[i + 1];
+                float pr = v0.x * t0, pi = v0.y * t0;
+                a0r += pr; a0i += pi;
+                pr = v1.x * t1; pi = v1.y * t1;
+                a1r += pr; a1i += pi;
+            }
+            for (; i < tpf; i++) {
+                float2 v0 = x[i];
+                float t0 = dt[i];
+                float pr = v0.x * t0, pi = v0.y * t0;
+                a0r += pr; a0i += pi;
+            }
+            slots[tx * MP + a.idxlut[j]] = make_float2(a0r + a1r, a0i + a1i);
+        }
+    }
+    __syncthreads();
+    if (active) {
+        const float2 *row = slots + tx * MP;
+        for (int k = ty; k < M; k += YS) {
+            float2 acc = make_float2(0.f, 0.f);
+            int ph = 0;                              // (s*k) mod M
+            for (int sidx = 0; sidx < M; ++sidx) {
+                float2 w = a.dft[ph];
+                float2 v = row[sidx];
+                acc.x = __builtin_fmaf(v.x, w.x, acc.x);
+                acc.x = __builtin_fmaf(-v.y, w.y, acc.x);
+                acc.y = __builtin_fmaf(v.x, w.y, acc.y);
+                acc.y = __builtin_fmaf(v.y, w.x, acc.y);
+                ph += k; if (ph >= M) ph -= M;
+            }
+            a.out[t * M + k] = acc;
+        }
+    }
+}
+
 int launch_pfb(const PfbArgs &a, hipStream_t st)
 {
     if (a.nout <= 0) return GRHIP_OK;
@@ -717,6 +785,15 @@ int launch_pfb(const PfbArgs &a, hipStream_t st)
         case 16: rc = launch_pfb_os1<16>(a, st); break;
         }
         if (rc != -1) return rc;
+    }
+    if (a.M <= 64) {
+        int ys = a.M < 16 ? a.M : 16;
+        dim3 block(64, ys);
+        dim3 grid((unsigned)((a.nout + 63) / 64));
+        size_t lds = (size_t)64 * (a.M + 1) * sizeof(float2);
+        hipLaunchKernelGGL(pfb_rows_kernel, grid, block, lds, st, a);
+        GRHIP_HIP(hipGetLastError());
+        return GRHIP_OK;
     }
     int ty = 256 / a.M; if (ty < 1) ty = 1;
     dim3 block(a.M, ty);
