@@ -480,8 +480,9 @@ __global__ void __launch_bounds__(64 * M) __attribute__((amdgpu_waves_per_eu(M =
 pfb_os1_kernel(const PfbArgs a, long long ntiles)
 {
     constexpr int R = 8, TT = 64 * R;                  // output vectors per tile
-    constexpr int LOGM = M == 1 ? 0 : M == 2 ? 1 : M == 4 ? 2 : M == 8 ? 3 : 4;
-    static_assert((1 << LOGM) == M, "M must be a power of two <= 16");
+    constexpr bool POW2 = (M & (M - 1)) == 0;          // otherwise (M = 3, 5, 6, ...): direct M x M DFT per output vector
+    constexpr int LOGM = M == 1 ? 0 : M == 2 ? 1 : M <= 4 ? 2 : M <= 8 ? 3 : 4;
+    static_assert(M >= 2 && M <= 16, "2 <= M <= 16");
     typedef float pfb_f32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int pfb_u32x4 __attribute__((ext_vector_type(4)));
     typedef float pfb_f32x4 __attribute__((ext_vector_type(4)));
@@ -604,6 +605,7 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
             const long long tt = t0 + tl;
             if (!COAL && tt >= a.nout) continue;
             float2 v[M];
+            if (POW2) {
             // bit-reversed load, then radix-2 decimation-in-time stages
 #pragma unroll
             for (int s = 0; s < M; ++s) {
@@ -633,6 +635,26 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
                     }
                 }
             }
+            } else {
+                // out[k] = sum_s slot[s] e^{+2 pi i s k / M}: M^2 complex multiply-adds, the M table entries wave-uniform
+                float2 u[M];
+#pragma unroll
+                for (int s = 0; s < M; ++s) { const pfb_f32x2 q = sl[(size_t)s * SS + tl + (tl >> 3)]; u[s] = make_float2(q.x, q.y); }
+#pragma unroll
+                for (int k = 0; k < M; ++k) {
+                    float2 acc = u[0];
+#pragma unroll
+                    for (int s = 1; s < M; ++s) {
+                        const int ph = (s * k) % M;
+                        const float wr = dft[2 * ph], wi = dft[2 * ph + 1];
+                        acc.x = __builtin_fmaf(u[s].x, wr, acc.x);
+                        acc.x = __builtin_fmaf(-u[s].y, wi, acc.x);
+                        acc.y = __builtin_fmaf(u[s].x, wi, acc.y);
+                        acc.y = __builtin_fmaf(u[s].y, wr, acc.y);
+                    }
+                    v[k] = acc;
+                }
+            }
             if (COAL) {
                 __syncthreads();                       // every wave has read its vectors' slots: the rows are free
                 pfb_f32x2 *sc = dst;                   // this wave's row, (M + 1) slots per vector
@@ -655,12 +677,13 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
                 continue;
             }
             float2 *o = a.out + tt * M;
-            if (M >= 2) {
+            if (M % 2 == 0) {
                 float4 *o4 = reinterpret_cast<float4 *>(o);
 #pragma unroll
-                for (int k = 0; k < M; k += 2) o4[k >> 1] = make_float4(v[k].x, v[k].y, v[k + 1].x, v[k + 1].y);
+                for (int k = 0; k + 1 < M; k += 2) o4[k >> 1] = make_float4(v[k].x, v[k].y, v[k + 1].x, v[k + 1].y);
             } else {
-                o[0] = v[0];
+#pragma unroll
+                for (int k = 0; k < M; ++k) o[k] = v[k];          // (an odd vector is not a whole number of 16-byte pieces)
             }
         }
         if (M != 8) __syncthreads();                   // sl (= xs) belongs to the next tile's samples from here
@@ -772,6 +795,18 @@ pfb_rows_kernel(const PfbArgs a)
     }
 }
 
+template <int M>
+static int launch_pfb_os1_any(const PfbArgs &a, hipStream_t st)
+{
+    const int R = 8, TT = 512;
+    const int tpfp = (a.tpf + R - 1) / R * R;
+    const int XS = (TT + tpfp + R) + (TT + tpfp + R) / R + 1;
+    const size_t lds = (size_t)M * XS * sizeof(float2) + (size_t)M * tpfp * sizeof(float);
+    if (lds > 150 * 1024 || tpfp > 256) return -1;
+    if ((a.nout + a.tpf) * 8 > 0xffffffffLL) return -1;
+    return launch_pfb_os1_nt<M, 0>(a, lds, st);
+}
+
 int launch_pfb(const PfbArgs &a, hipStream_t st)
 {
     if (a.nout <= 0) return GRHIP_OK;
@@ -783,6 +818,18 @@ int launch_pfb(const PfbArgs &a, hipStream_t st)
         case 4: rc = launch_pfb_os1<4>(a, st); break;
         case 8: rc = launch_pfb_os1<8>(a, st); break;
         case 16: rc = launch_pfb_os1<16>(a, st); break;
+        // channel counts that are not a power of two: the same kernel with a direct DFT (taps in LDS, any filter length)
+        case 3: rc = launch_pfb_os1_any<3>(a, st); break;
+        case 5: rc = launch_pfb_os1_any<5>(a, st); break;
+        case 6: rc = launch_pfb_os1_any<6>(a, st); break;
+        case 7: rc = launch_pfb_os1_any<7>(a, st); break;
+        case 9: rc = launch_pfb_os1_any<9>(a, st); break;
+        case 10: rc = launch_pfb_os1_any<10>(a, st); break;
+        case 11: rc = launch_pfb_os1_any<11>(a, st); break;
+        case 12: rc = launch_pfb_os1_any<12>(a, st); break;
+        case 13: rc = launch_pfb_os1_any<13>(a, st); break;
+        case 14: rc = launch_pfb_os1_any<14>(a, st); break;
+        case 15: rc = launch_pfb_os1_any<15>(a, st); break;
         }
         if (rc != -1) return rc;
     }

@@ -99,7 +99,8 @@ def _pfb_streams(x, M, tpf):
     return [np.concatenate([np.zeros(tpf, np.complex64), x[j::M]]) for j in range(M)]
 
 
-@pytest.mark.parametrize("M,ntaps", [(8, 256), (8, 250), (4, 33), (16, 64), (3, 10), (1, 5)])
+@pytest.mark.parametrize("M,ntaps", [(8, 256), (8, 250), (4, 33), (16, 64), (3, 10), (1, 5), (5, 100), (6, 50), (7, 7), (9, 300),
+                                     (10, 200), (11, 33), (12, 96), (13, 130), (14, 28), (15, 64), (20, 100), (32, 64)])
 def test_pfb_vs_oracle(gpu, po, M, ntaps):
     rng = np.random.default_rng(M * 1000 + ntaps)
     nout = 1500
@@ -119,7 +120,7 @@ def test_pfb_vs_oracle(gpu, po, M, ntaps):
 
 
 @pytest.mark.parametrize("M,tpf,nout", [(8, 32, 512 * 2400 + 77), (8, 8, 512 * 1600 + 1), (8, 48, 512 * 800 + 63),
-                                        (4, 32, 512 * 3200 + 5)])
+                                        (4, 32, 512 * 3200 + 5), (10, 20, 512 * 1500 + 9), (5, 33, 512 * 2000 + 311)])
 def test_pfb_persistent_walk(gpu, po, M, tpf, nout):
     """more tiles than resident workgroups: every workgroup walks several tiles (the next tile's samples in flight), and a
     ragged last tile whose vectors past nout fall outside the store descriptor; tpf 32 / 8: taps resident in SGPRs,

@@ -10,8 +10,8 @@ wl = g.workload
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev)
 tot = 1 << 26
-for M, tpf in ((2, 32), (4, 32), (8, 32), (16, 32), (8, 64), (8, 16), (32, 16), (5, 20)):
-    nout = tot // M
+for M, tpf in ((2, 32), (4, 32), (8, 32), (16, 32), (8, 64), (8, 16), (32, 16), (5, 20), (10, 20), (12, 32), (15, 16)):
+    nout = (tot // M) // 512 * 512
     taps = wl.lowpass_taps(M * tpf, 0.5 / M, 1.0)
     pf = g.pfb_channelizer_ccf(M, taps, 1.0)
     per = nout + 128
