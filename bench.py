@@ -412,6 +412,24 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
     elapsed = gd.max_over_ranks(elapsed, dist, dev)
 
+    # the same step on the vector-FMA engine (the north star's "no MFMA" form), reported beside the headline: a few
+    # untimed steps for the clocks, then the same K steps under HIP events
+    valu_ms = None
+    if a.engine == "fast" and not a.per_capture_launch:
+        blk.set_mode(g.MODE_FAST_VALU)
+        for _ in range(max(a.warmup, 3)):
+            step()
+        torch.cuda.synchronize()
+        ev2 = torch.cuda.Event(enable_timing=True)
+        ev3 = torch.cuda.Event(enable_timing=True)
+        ev2.record(stream)
+        for _ in range(a.steps):
+            step()
+        ev3.record(stream)
+        torch.cuda.synchronize()
+        valu_ms = ev2.elapsed_time(ev3) / a.steps
+        blk.set_mode(g.MODE_FAST)
+
     if rank == 0:
         total_samples = float(world) * B * n * a.steps
         value = total_samples / elapsed / 1e6
@@ -448,6 +466,11 @@ def main():
                          "mfma_f16_tflops": mfma_flops / (k_ms * 1e-3) / 1e12,
                          "frac_of_f16_mfma_peak": mfma_flops / (k_ms * 1e-3) / 1e12 / 2500.0},
         }
+        if valu_ms is not None:
+            res["vector_engine"] = {"engine": "GRHIP_MODE_FAST_VALU (f32 vector FMAs, no matrix cores), same step, rank 0",
+                                    "kernel": "fir_tiled_kernel<D=4,premix,demod>", "kernel_ms": valu_ms,
+                                    "Msamples_per_s_per_gpu": B * n / valu_ms / 1e3,
+                                    "frac": alg_bytes / (valu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, x0_host[: a.cpu_samples], proto)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
