@@ -355,7 +355,7 @@ int launch_fft(int N, int forward, int shift, const float *window, const float2 
     if (nvec <= 0) return GRHIP_OK;
     if (!fft_size_supported(N)) return fail(GRHIP_EINVAL, "fft size %d not supported on device", N);
     if (N == 8192) return launch_fft8192(forward, shift, window, twiddle, in, out, nvec, st);
-    if (N == 256 || N == 512 || N == 1024 || N == 2048) return launch_fft16x(N, forward, shift, window, twiddle, in, out, nvec, st);
+    if (N >= 32 && N <= 2048) return launch_fft16x(N, forward, shift, window, twiddle, in, out, nvec, st);
     if (N == 4096) {
         if (nvec > 0x7fffffffLL) return fail(GRHIP_EINVAL, "fft: too many vectors in one call");
         if (forward) launch_fft4096<true>(shift, window, twiddle, in, out, nvec, st);
@@ -913,9 +913,9 @@ __device__ __forceinline__ void fft4096_mid_passes(f32x2_t (&v)[16], f32x2_t *S,
 }
 
 // ===========================================================================
-// gr_fft_vcc, N = 256, 512, 1024, 2048: the radix-16 register kernel with N / 16 lanes per vector (a 256-lane workgroup
-// carries 4096 / N vectors at a time): two radix-16 passes and one pass of radix R3 = N / 256 (none for 256) in which a
-// lane does 16 / R3 butterflies on the sixteen points it holds.  Every pass reads point q of lane l at l + (N/16) q of its
+// gr_fft_vcc, N = 32 ... 2048: the radix-16 register kernel with N / 16 lanes per vector (a 256-lane workgroup carries
+// 4096 / N vectors at a time): two radix-16 passes (one below 256 points) and one pass of radix R3 = N / 256 (N / 16
+// below 256 points; none for 256) in which a lane does 16 / R3 butterflies on the sixteen points it holds.  Every pass reads point q of lane l at l + (N/16) q of its
 // vector (pass 1: straight from HBM), so the three passes share one index pattern; the last writes HBM directly.
 // Persistent workgroups, next group's points requested one group ahead, middle-pass twiddles in LDS, last-pass twiddles
 // in registers -- as fft4096_kernel.  (The radix-4 LDS kernel these sizes used before fetched three twiddles per
@@ -953,7 +953,9 @@ fft16x_kernel(const float *__restrict__ window, const float2 *__restrict__ twidd
 {
     constexpr int LPV = N / 16;                 // lanes per vector
     constexpr int VPG = 256 / LPV;              // vectors per workgroup step
-    constexpr int R3 = N / 256;                 // radix of the third pass (1: none)
+    constexpr bool TWO = N >= 256;              // two radix-16 passes (N = 32, 64, 128: one, then the radix N / 16 pass)
+    constexpr int P3 = TWO ? 256 : 16;          // transform length done before the last pass
+    constexpr int R3 = N / P3;                  // radix of the last pass (1: none)
     constexpr int NB3 = R3 > 1 ? 16 / R3 : 0;   // its butterflies per lane
     constexpr int VS = N + N / 16;              // LDS slots per vector (one pad slot per 16)
     __shared__ f32x2_t S[VPG * VS];
@@ -977,7 +979,7 @@ fft16x_kernel(const float *__restrict__ window, const float2 *__restrict__ twidd
         for (int b = 0; b < NB3; ++b)
 #pragma unroll
             for (int m = 1; m < R3; ++m) {
-                const int k = (l + LPV * b) & 255;
+                const int k = (l + LPV * b) & (P3 - 1);
                 const float2 w = twiddle[(k * m) & (N - 1)];
                 w3[b * (R3 - 1) + m - 1] = f32x2_t{w.x, w.y};
             }
@@ -1013,10 +1015,10 @@ fft16x_kernel(const float *__restrict__ window, const float2 *__restrict__ twidd
         __syncthreads();
         if (grp + gridDim.x < ngroups) request(grp + gridDim.x);
         // ---- pass 2 (p = 16)
-        {
+        if (TWO) {
             const int k = l & 15;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = Sv[l + (l >> 4) + (LPV + LPV / 16) * q];
+            for (int q = 0; q < 16; ++q) v[q] = Sv[l + LPV * q + (LPV >= 16 ? (l >> 4) + (LPV / 16) * q : (LPV * q) / 16)];
             __syncthreads();
 #pragma unroll
             for (int q0 = 0; q0 < 16; q0 += 2) {
@@ -1032,19 +1034,21 @@ fft16x_kernel(const float *__restrict__ window, const float2 *__restrict__ twidd
                                                                            (int)(left < (long long)VPG * N * 8 ? left : (long long)VPG * N * 8), 0x00020000);
         (void)vec;
         const int j2 = (l - (l & 15)) * 16 + (l & 15);          // pass 2 writes element j2 + 16 m
-        if (R3 == 1) {
+        if (TWO && R3 == 1) {
             // N = 256: pass 2 is the last one; a shift by N / 2 = 128 = 16 * 8 is m ^ 8
 #pragma unroll
             for (int m = 0; m < 16; ++m)
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v[m]), yr, 8 * (vl * N + j2), 8 * 16 * (m ^ (SHIFT_OUT ? 8 : 0)), 0);
             continue;
         }
+        if (TWO) {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) Sv[j2 + (j2 >> 4) + 17 * m] = v[m];
-        __syncthreads();
-        // ---- pass 3 (p = 256, radix R3): butterfly b works on points q = b + NB3 m
+            for (int m = 0; m < 16; ++m) Sv[j2 + (j2 >> 4) + 17 * m] = v[m];
+            __syncthreads();
+        }
+        // ---- last pass (p = P3, radix R3): butterfly b works on points q = b + NB3 m
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = Sv[l + (l >> 4) + (LPV + LPV / 16) * q];
+        for (int q = 0; q < 16; ++q) v[q] = Sv[l + LPV * q + (LPV >= 16 ? (l >> 4) + (LPV / 16) * q : (LPV * q) / 16)];
         __syncthreads();                                        // S belongs to the next group from here
 #pragma unroll
         for (int b = 0; b < NB3; ++b) {
@@ -1056,12 +1060,12 @@ fft16x_kernel(const float *__restrict__ window, const float2 *__restrict__ twidd
             if (R3 == 2) radix2<FWD>(v[b], v[b + NB3]);
             if (R3 == 4) radix4<FWD>(v[b], v[b + NB3], v[b + 2 * NB3], v[b + 3 * NB3]);
             if (R3 == 8) dft8<FWD>(v[b], v[b + NB3], v[b + 2 * NB3], v[b + 3 * NB3], v[b + 4 * NB3], v[b + 5 * NB3], v[b + 6 * NB3], v[b + 7 * NB3]);
-            // output m of the butterfly is element j + 256 m, i = l + LPV b, k = i mod 256, j = (i - k) R3 + k
-            const int i = l + LPV * b, k = i & 255, j = (i - k) * R3 + k;
+            // output m of the butterfly is element j + P3 m, i = l + LPV b, k = i mod P3, j = (i - k) R3 + k
+            const int i = l + LPV * b, k = i & (P3 - 1), j = (i - k) * R3 + k;
 #pragma unroll
             for (int m = 0; m < R3; ++m)
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v[b + NB3 * m]), yr, 8 * (vl * N + j),
-                                                      8 * 256 * (m ^ (SHIFT_OUT ? R3 / 2 : 0)), 0);
+                                                      8 * P3 * (m ^ (SHIFT_OUT ? R3 / 2 : 0)), 0);
         }
     }
 }
@@ -1090,6 +1094,9 @@ static int launch_fft16x(int N, int forward, int shift, const float *window, con
 #define GRHIP_FFT16X(NN) do { if (forward) launch_fft16x_t<NN, true>(shift, window, twiddle, in, out, nvec, st); \
                               else launch_fft16x_t<NN, false>(shift, window, twiddle, in, out, nvec, st); } while (0)
     switch (N) {
+    case 32: GRHIP_FFT16X(32); break;
+    case 64: GRHIP_FFT16X(64); break;
+    case 128: GRHIP_FFT16X(128); break;
     case 256: GRHIP_FFT16X(256); break;
     case 512: GRHIP_FFT16X(512); break;
     case 1024: GRHIP_FFT16X(1024); break;

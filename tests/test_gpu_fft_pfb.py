@@ -31,7 +31,7 @@ def test_fft_reference_qa_vectors(gpu):
     assert np.all(np.abs(back - src) <= v["abs_eps"] + v["rel_eps"] * np.abs(src))
 
 
-@pytest.mark.parametrize("N", [1, 2, 4, 8, 16, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("N", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
 @pytest.mark.parametrize("forward", [True, False])
 def test_fft_sizes_vs_oracle(gpu, po, N, forward):
     rng = np.random.default_rng(N + int(forward))
@@ -44,7 +44,7 @@ def test_fft_sizes_vs_oracle(gpu, po, N, forward):
 
 @pytest.mark.parametrize("forward,shift,win", [(True, True, False), (False, True, False), (True, False, True),
                                                (False, True, True), (True, True, True)])
-@pytest.mark.parametrize("N,nvec", [(128, 5), (256, 7), (512, 9), (1024, 5), (2048, 3), (4096, 3), (8192, 3)])     # from 256 on: the radix-16 kernels
+@pytest.mark.parametrize("N,nvec", [(16, 9), (32, 133), (64, 11), (128, 5), (256, 7), (512, 9), (1024, 5), (2048, 3), (4096, 3), (8192, 3)])     # from 32 on: the radix-16 kernels
 def test_fft_window_and_shift(gpu, po, forward, shift, win, N, nvec):
     rng = np.random.default_rng(5)
     x = _rc(rng, N * nvec)
@@ -57,7 +57,7 @@ def test_fft_window_and_shift(gpu, po, forward, shift, win, N, nvec):
     assert blk.set_window(np.ones(N, np.float32)) is True
 
 
-@pytest.mark.parametrize("N,nvec", [(256, 40_003), (512, 19_999), (1024, 9001), (2048, 4001), (4096, 2100), (8192, 1700)])
+@pytest.mark.parametrize("N,nvec", [(32, 300_001), (128, 80_003), (256, 40_003), (512, 19_999), (1024, 9001), (2048, 4001), (4096, 2100), (8192, 1700)])
 @pytest.mark.parametrize("forward,shift,win", [(True, False, False), (False, True, False), (True, True, True)])
 def test_fft4096_persistent_walk(gpu, po, forward, shift, win, N, nvec):
     """more vectors than resident workgroups (4 per CU plain, 3 windowed; 8192 points: 3 and 2): every workgroup walks

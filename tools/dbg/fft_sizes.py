@@ -8,7 +8,7 @@ g = grhip_loader.import_grhip()
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev)
 tot = 1 << 26
-for N in (64, 256, 512, 1024, 2048, 4096, 8192):
+for N in (16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
     nvec = tot // N
     x = torch.randn((tot, 2), device=dev); y = torch.empty((tot, 2), device=dev)
     f = g.fft_vcc(N, True, [], False)
