@@ -268,11 +268,19 @@ int XlatingCore::ensure_rot(long long n, const float2 **gtab, hipStream_t st)
         float pr = gen_phase.real(), pi = gen_phase.imag();
         const float ir = incr.real(), ii = incr.imag();
         unsigned cnt = gen_counter;
-        for (long long i = 0; i < need; ++i) {
-            fresh[(size_t)i] = cf(pr, pi);
-            cnt++;
-            float ac = pr * ir, bd = pi * ii, ad = pr * ii, bc = pi * ir;
-            pr = ac - bd; pi = ad + bc;
+        // (runs of steps up to the next multiple of 512 without the counter test inside: the recurrence is a serial chain
+        // of one multiply and one add per step, and this loop is what a streaming stand-alone xlating block waits for)
+        for (long long i = 0; i < need;) {
+            long long run = 512 - (long long)(cnt % 512);
+            if (run > need - i) run = need - i;
+            cf *dstp = fresh.data() + (size_t)i;
+            for (long long r = 0; r < run; ++r) {
+                dstp[r] = cf(pr, pi);
+                const float ac = pr * ir, bd = pi * ii, ad = pr * ii, bc = pi * ir;
+                pr = ac - bd; pi = ad + bc;
+            }
+            i += run;
+            cnt += (unsigned)run;
             if ((cnt % 512) == 0) {
                 float a = hypotf(pr, pi);
                 pr = pr / a; pi = pi / a;
