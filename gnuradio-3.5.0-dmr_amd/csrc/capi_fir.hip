@@ -214,6 +214,13 @@ int XlatingCore::build(int device)
     // taps per polyphase component (tools/bench_decim.py)
     hidec_premix = real_proto && ntaps > 0 && ntaps / decim >= 16;
     use_hidec = !use_tiled && hidec_wanted(decim, ntaps, !hidec_premix, use_ols);
+    if (for_demod && real_proto && ntaps > 0) {
+        // a demodulating handle: whatever engine has the fused demodulator (see xlating_core.h)
+        if (use_tiled && premix) prefer_ols = false;
+        // (up to 1024 taps: beyond, the f32 direct sum of the pre-mixed products leaves the 1e-5 tolerance -- 1.04e-5 measured
+        // at 1200 taps -- and the engine, with its host-side rotator phases, stays)
+        else if (!use_tiled && ntaps <= 1024 && hidec_supported(decim, ntaps)) { hidec_premix = true; use_hidec = true; }
+    }
     if (use_hidec) {
         std::vector<float> hp2;
         if (hidec_premix) {
@@ -338,8 +345,10 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
     const bool demod = d_demod != nullptr;
     const bool batched = !(n_streams == 1 && n_lo == 0);
     const bool mfma_now = mode_matrix(mode) && use_mfma && (n_streams == 1 || !(x_stride & 1));
+    // fused demodulator of the high-decimation direct kernel (pre-mix form): no rotator phases either
+    const bool hidec_direct = !mfma_now && demod && mode_fast(mode) && use_hidec && hidec_premix && !batched;
     const bool direct = mfma_now ? demod
-                                 : (demod && mode_fast(mode) && use_tiled && premix && (batched || !prefer_ols));
+                                 : (hidec_direct || (demod && mode_fast(mode) && use_tiled && premix && (batched || !prefer_ols)));
     int rc = GRHIP_OK;
     if (!direct) {          // the direct demodulator epilogue needs no rotator phases
         rc = ensure_rot(n_out, &gtab, st);
@@ -361,6 +370,13 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         a.sched = mf_sched.get();
         a.max_wg_per_cu = mf_wg_cap;
         rc = launch_fir_mfma(decim, ntaps, true, demod ? EPI_DEMOD : EPI_ROTATE, a, st);
+        if (rc) return rc;
+        pos += n_out;
+        return GRHIP_OK;
+    }
+    if (hidec_direct) {
+        rc = launch_fir_hidec_demod(d_hidec_taps.as<float>(), ntaps, decim, d_in, (n_out - 1) * decim + ntaps, d_demod, n_out, gain,
+                                    y_prev, y_last, atan_tab, d_hidec_etab.as<float2>(), d_hidec_vtab.as<float2>(), st);
         if (rc) return rc;
         pos += n_out;
         return GRHIP_OK;
@@ -1122,6 +1138,7 @@ int grhip_xlating_demod_create(grhip_xlating_demod **h, int decimation, const fl
     if (!rc) rc = get_device_tables(device, &x->tabs);
     if (!rc) {
         x->core.decim = decimation;
+        x->core.for_demod = true;
         x->core.proto.assign((const cf *)taps, (const cf *)taps + ntaps);
         x->core.center_freq = center_freq; x->core.sampling_freq = sampling_freq;
         rc = x->core.build(device);

@@ -303,12 +303,25 @@ bool hidec_supported(int D, int ntaps)
 // ahead into registers through a range-checked buffer descriptor; the pre-mix phasors of a lane's samples are tile
 // independent and stay in registers; the taps sit in LDS (uniform-address reads: in-order with the sample reads, so the
 // waits are counted -- as scalar loads they shared a counter that can only be waited to zero); all 256 lanes compute.
-template <bool CTAPS, int V1, bool PREMIX>
+// DEMOD (pre-mix form only): the fused xlating -> quadrature demodulator of the other decimations.  As in the tiled and the
+// matrix-core kernels the demodulator works directly on the pre-mixed accumulators (the pre-mix correction e^{-jwD} and
+// the rotator step e^{+jwD} cancel in y[n] conj(y[n-1])): no rotator table, no intermediate in HBM.  Tiles overlap by one
+// output pair (lane 0 computes it only to hand its second output on), the first output of a call takes the previous
+// call's last composite output (y_prev) brought into the tile's frame, the call's last composite output goes to y_last.
+struct HidecAtan {
+    const float2 *p;
+    __device__ __forceinline__ float2 operator[](int k) const { return p[k]; }
+};
+
+template <bool CTAPS, int V1, bool PREMIX, bool DEMOD = false>
 __global__ void __launch_bounds__(256, 3)
 fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__restrict__ taps_g, int ntaps, int D,
                  int G, long long n_out, float2 *__restrict__ y, const float2 *__restrict__ gtab,
-                 const float2 *__restrict__ etab, const float2 *__restrict__ vtab, long long ntiles)
+                 const float2 *__restrict__ etab, const float2 *__restrict__ vtab, long long ntiles,
+                 float *__restrict__ d_out = nullptr, float gain = 0.f, const float2 *__restrict__ y_prev = nullptr,
+                 float2 *__restrict__ y_last = nullptr, const float *__restrict__ atan_tab = nullptr)
 {
+    static_assert(!DEMOD || (PREMIX && !CTAPS), "the fused demodulator belongs to the pre-mix form");
     extern __shared__ __attribute__((aligned(16))) unsigned char hidec_smem[];
     typedef float hd_f32x2 __attribute__((ext_vector_type(2)));
     typedef float hd_f32x4 __attribute__((ext_vector_type(4)));
@@ -347,19 +360,21 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(gtab), 0, gtab ? (int)(n_out * 8) : 0, 0x00020000);
     hd_f32x2 pre[HIDEC_NR];
     hd_f32x4 gq{1.f, 0.f, 1.f, 0.f};
+    const int TNEW = DEMOD ? Tn - 2 : Tn;            // new outputs per tile
     auto request = [&](long long tile) __attribute__((always_inline)) {
         int tq = t;
         asm volatile("" : "+v"(tq));                 // (offsets per tile: hoisted, they would be spilled)
-        const long long u0 = tile * Tn * D;
+        const long long u0 = (tile * TNEW - (DEMOD ? 2 : 0)) * D;     // (DEMOD: the first tile starts two outputs early)
+        const int first = u0 < 0 ? (int)-u0 : 0;     // samples before the stream: explicit out-of-range offsets
         const int vo = (int)(u0 * 8) + 8 * tq;
 #pragma unroll
         for (int i = 0; i < HIDEC_NR; ++i) {
             if (256 * i < ns) {                      // (wave-uniform: rounds past the tile are skipped, not loaded out of range)
-                const int off = (tq + 256 * i < ns) ? vo + 2048 * i : 0x7ffffff0;
+                const int off = (tq + 256 * i < ns && tq + 256 * i >= first) ? vo + 2048 * i : 0x7ffffff0;
                 pre[i] = __builtin_bit_cast(hd_f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
             }
         }
-        if (gtab) {
+        if (!DEMOD && gtab) {
             const long long n = tile * Tn + 2 * tp;
             // (two 8-byte loads: an odd n_out ends in the middle of the pair)
             const hd_f32x2 g0 = __builtin_bit_cast(hd_f32x2, __builtin_amdgcn_raw_buffer_load_b64(gr, (int)(n * 8), 0, 0));
@@ -416,10 +431,13 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
             }
         }
         // ---- the groups' partial sums meet in LDS (the sample area is free once every lane is through its MACs)
-        if (G > 1) {
+        hd_f32x4 *red = reinterpret_cast<hd_f32x4 *>(xs);
+        float2 *carry = reinterpret_cast<float2 *>(xs) + 1024;          // DEMOD: second output of every pair (2 KB, behind the partial sums)
+        float2 *atp = reinterpret_cast<float2 *>(xs) + 2048;            // DEMOD: the arctangent table as (tab[k], tab[k+1]) pairs
+        if (G > 1 || DEMOD) {
             __syncthreads();
-            hd_f32x4 *red = reinterpret_cast<hd_f32x4 *>(xs);
             if (grp > 0 && !idle) red[(grp - 1) * LG + tp] = hd_f32x4{a0x, a0y, a1x, a1y};
+            if (DEMOD) atp[t] = make_float2(atan_tab[t], atan_tab[t + 1]);
             __syncthreads();
             if (grp == 0) {
                 for (int g2 = 1; g2 < G; ++g2) {
@@ -428,7 +446,40 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
                 }
             }
         }
-        if (grp == 0) {
+        if (DEMOD) {
+            if (grp == 0) carry[tp] = make_float2(a1x, a1y);
+            __syncthreads();
+            if (grp == 0) {
+                const long long n = tile * TNEW - 2 + 2 * tp;           // outputs n, n + 1 (lane 0: the overlap pair)
+                float2 prev = tp > 0 ? carry[tp - 1] : make_float2(0.f, 0.f);
+                if (tile == 0 && tp == 1) {
+                    // predecessor of the call's first output: the previous call's last composite output y_bp[-1], in this
+                    // tile's frame a_m = e^{+jw m D} y_bp (m = 1 for output -1); a fresh stream has none: zero
+                    prev = make_float2(0.f, 0.f);
+                    if (y_prev) {
+                        const float2 yp = y_prev[0], v1 = vtab[1];
+                        prev = cmul_ref(yp, make_float2(v1.x, -v1.y));
+                    }
+                }
+                const HidecAtan tabv{atp};
+                const float2 a0 = make_float2(a0x, a0y), a1 = make_float2(a1x, a1y);
+                const float d0 = quad_demod_fast(a0, prev, gain, tabv);
+                const float d1 = quad_demod_fast(a1, a0, gain, tabv);
+                if (tp > 0) {
+                    if (n + 1 < n_out && ((((uintptr_t)(d_out + n)) & 7) == 0)) {
+                        *reinterpret_cast<float2 *>(d_out + n) = make_float2(d0, d1);
+                    } else {
+                        if (n < n_out) d_out[n] = d0;
+                        if (n + 1 < n_out) d_out[n + 1] = d1;
+                    }
+                    // the call's last composite output, for the next call
+                    if (y_last && (n == n_out - 1 || n + 1 == n_out - 1)) {
+                        const bool second = n + 1 == n_out - 1;
+                        y_last[0] = cmul_ref(second ? a1 : a0, second ? make_float2(v1c.x, v1c.y) : make_float2(v0c.x, v0c.y));
+                    }
+                }
+            }
+        } else if (grp == 0) {
             const long long n = tile * Tn + 2 * tp;
             float2 a0 = make_float2(a0x, a0y), a1 = make_float2(a1x, a1y);
             if (PREMIX) {
@@ -493,6 +544,43 @@ int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim,
     else { GRHIP_HIDEC_V(false, false) }
 #undef GRHIP_HIDEC_V
 #undef GRHIP_HIDEC
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
+int launch_fir_hidec_demod(const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in, float *d_out,
+                           long long n_out, float gain, const float2 *y_prev, float2 *y_last, const float *atan_tab,
+                           const float2 *etab, const float2 *vtab, hipStream_t st)
+{
+    if (n_out <= 0) return GRHIP_OK;
+    if (!hidec_supported(decim, ntaps) || n_in < 1 || !etab || !vtab || !atan_tab)
+        return fail(GRHIP_EINVAL, "high-decimation FIR + demodulator: unsupported shape");
+    if (n_in * 8 > 0x7fffffffLL) return fail(GRHIP_EINVAL, "high-decimation FIR: more than 2 GB of items in one call");
+    const int G = hidec_groups(decim, ntaps);
+    const int Tn = 2 * (256 / G);
+    const long long ntiles = (n_out + (Tn - 2) - 1) / (Tn - 2);
+    const int v1 = hidec_sub_log(decim);
+    const int nsub = 1 << v1, sub = ((HIDEC_LDS_SAMPLES >> v1) + 2) | 1;
+    const size_t lds = (size_t)nsub * sub * 8 + (size_t)(ntaps + 2 * decim + 64) * 4;
+    int dev = 0, n_cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus < 1)
+        n_cus = 256;
+    const long long per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
+    const long long cap = per_cu * n_cus;
+    const unsigned blocks = (unsigned)(ntiles < cap ? ntiles : cap);
+#define GRHIP_HIDEC_D(V)                                                                                                \
+    do {                                                                                                                \
+        static size_t cfg = 0;                                                                                          \
+        if (lds > 48 * 1024 && lds > cfg) {                                                                             \
+            GRHIP_HIP(hipFuncSetAttribute((const void *)fir_hidec_kernel<false, V, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            cfg = lds;                                                                                                  \
+        }                                                                                                               \
+        hipLaunchKernelGGL((fir_hidec_kernel<false, V, true, true>), dim3(blocks), dim3(256), lds, st, x, n_in, taps_padded, ntaps, decim, \
+                           G, n_out, (float2 *)nullptr, (const float2 *)nullptr, etab, vtab, ntiles, d_out, gain, y_prev, y_last, atan_tab); \
+    } while (0)
+    switch (v1) { case 1: GRHIP_HIDEC_D(1); break; case 2: GRHIP_HIDEC_D(2); break; case 3: GRHIP_HIDEC_D(3); break;
+                  case 4: GRHIP_HIDEC_D(4); break; default: GRHIP_HIDEC_D(5); break; }
+#undef GRHIP_HIDEC_D
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
 }

@@ -23,6 +23,10 @@ struct XlatingCore {
     std::vector<std::complex<float>> proto;
     double center_freq = 0, sampling_freq = 1;
 
+    // set before build(): the handle only ever demodulates (xlating_demod, dmr_chain).  Its FAST dispatch then prefers the
+    // engines with a fused demodulator -- they need no rotator phases, whose exact recurrence is computed on the host at
+    // ~3 ns per output and bounds a STREAMING block on any other path (measured: 1-8 Gsamples/s against 200-320)
+    bool for_demod = false;
     // built by build()
     int ntaps = 0;
     std::vector<std::complex<float>> ctaps;     // composite taps, reference arithmetic
@@ -87,6 +91,7 @@ struct XlatingCore {
     bool demod_is_direct(int mode, bool demod, bool batched = false) const
     {
         if (demod && mode_matrix(mode) && use_mfma) return true;
+        if (demod && mode_fast(mode) && use_hidec && hidec_premix && !batched) return true;     // the direct kernel's fused demodulator
         return demod && mode_fast(mode) && use_tiled && premix && (batched || !prefer_ols);
     }
     // d_in item 0 = input[0] of output 0 (oldest history item); items with index

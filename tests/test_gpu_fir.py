@@ -124,6 +124,34 @@ def test_overlap_save_engine_call_longer_than_2GB(gpu, po):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("decim,ntaps", [(10, 200), (20, 400), (8, 64)])
+def test_fused_demod_other_decimations_stream_and_switch_modes(gpu, po, wl, decim, ntaps):
+    """the fused xlating -> demodulator block at decimations the tiled / matrix-core kernels do not take: the direct kernel's
+    own demodulator epilogue (no rotator table), in calls of odd sizes with the one-sample carry between them, switching to
+    the bit-exact mode and back in mid-stream (the carry changes frame)"""
+    c = wl.CFG2
+    n = 1_200_000 // decim * decim
+    x = wl.fsk4_capture(n, stream_id=4)
+    proto = wl.lowpass_taps(ntaps, 100e3, 10e6).astype(np.complex64)
+    ref = po.chain_xlating_demod(decim, proto, c["center_freq"], c["fs"], 3.0, x)
+    nout = n // decim
+    hist = ntaps - 1
+    xin = wl.with_history(x, hist)
+    blk = gpu.xlating_demod(decim, proto, c["center_freq"], c["fs"], 3.0)
+    pieces = [1, 2, 255, 256, 257, 511, 513, 10_001, 1, 33_333]
+    modes = [gpu.MODE_FAST, gpu.MODE_FAST, gpu.MODE_GENERIC, gpu.MODE_FAST, gpu.MODE_FAST_VALU]
+    out, pos, k = [], 0, 0
+    while pos < nout:
+        m = min(pieces[k % len(pieces)], nout - pos)
+        blk.set_mode(modes[k % len(modes)])
+        out.append(blk.work(m, xin[pos * decim: pos * decim + m * decim + hist]))
+        pos += m
+        k += 1
+    got = np.concatenate(out)
+    ok, worst = demod_close(got, ref, skip=max(64, ntaps // decim + 1), gain=3.0)
+    assert ok, worst
+
+
 def test_fir_integer_data_exact_all_modes(gpu, po):
     """integer-valued data: every summation order is exact
     (filter/qa_gr_fir_ccf.cc:103-159 uses the same trick)"""
