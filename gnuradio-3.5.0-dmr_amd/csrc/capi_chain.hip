@@ -80,9 +80,10 @@ int grhip_dmr_chain_create(grhip_dmr_chain **h, const grhip_dmr_chain_params *p,
         c->core.decim = p->decimation;
         c->core.proto.assign((const std::complex<float> *)p->taps, (const std::complex<float> *)p->taps + p->ntaps);
         c->core.center_freq = p->center_freq; c->core.sampling_freq = p->sampling_freq;
+        c->core.for_demod = true;           // decimations other than 1/2/4: the direct kernel with the fused demodulator
         rc = c->core.build(device);
     }
-    if (!rc && !c->core.use_tiled && !c->core.use_mfma)
+    if (!rc && !c->core.use_tiled && !c->core.use_mfma && !(c->core.use_hidec && c->core.hidec_premix))
         rc = fail(GRHIP_EINVAL, "dmr_chain needs a decimation/tap count a batched FIR engine supports");
     if (!rc) {
         hipError_t e = hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking);

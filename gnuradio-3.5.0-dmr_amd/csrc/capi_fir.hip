@@ -346,7 +346,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
     const bool batched = !(n_streams == 1 && n_lo == 0);
     const bool mfma_now = mode_matrix(mode) && use_mfma && (n_streams == 1 || !(x_stride & 1));
     // fused demodulator of the high-decimation direct kernel (pre-mix form): no rotator phases either
-    const bool hidec_direct = !mfma_now && demod && mode_fast(mode) && use_hidec && hidec_premix && !batched;
+    const bool hidec_direct = !mfma_now && demod && mode_fast(mode) && use_hidec && hidec_premix;
     const bool direct = mfma_now ? demod
                                  : (hidec_direct || (demod && mode_fast(mode) && use_tiled && premix && (batched || !prefer_ols)));
     int rc = GRHIP_OK;
@@ -375,8 +375,9 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         return GRHIP_OK;
     }
     if (hidec_direct) {
-        rc = launch_fir_hidec_demod(d_hidec_taps.as<float>(), ntaps, decim, d_in, (n_out - 1) * decim + ntaps, d_demod, n_out, gain,
-                                    y_prev, y_last, atan_tab, d_hidec_etab.as<float2>(), d_hidec_vtab.as<float2>(), st);
+        rc = launch_fir_hidec_demod(d_hidec_taps.as<float>(), ntaps, decim, d_in, batched ? n_in : (n_out - 1) * decim + ntaps,
+                                    d_demod, n_out, gain, y_prev, y_last, atan_tab, d_hidec_etab.as<float2>(),
+                                    d_hidec_vtab.as<float2>(), st, n_streams, x_stride, out_stride, n_lo, mf_wg_cap);
         if (rc) return rc;
         pos += n_out;
         return GRHIP_OK;
@@ -1221,7 +1222,8 @@ int grhip_xlating_demod_run_captures_device(grhip_xlating_demod *h, int n_stream
     if (rc) return rc;
     const long long n_out = (long long)(n_samples / (size_t)h->core.decim);
     if (n_out <= 0) return GRHIP_OK;
-    if (!(mode_fast(h->mode) && (h->core.use_tiled || (mode_matrix(h->mode) && h->core.use_mfma))))
+    if (!(mode_fast(h->mode) && (h->core.use_tiled || (mode_matrix(h->mode) && h->core.use_mfma) ||
+                                 (h->core.use_hidec && h->core.hidec_premix))))
         return fail(GRHIP_EINVAL, "run_captures needs a batched engine (FAST mode, supported decimation)");
     if (h->core.tab_start != 0 && !h->core.demod_is_direct(h->mode, true, true))
         return fail(GRHIP_EINVAL, "handle has streamed past its cached rotator table; use a fresh handle");

@@ -105,7 +105,8 @@ void hidec_premix_tables(double omega, int decim, std::vector<float> &etab, std:
 // fused xlating -> quadrature demodulator of the pre-mix form (real prototype): d_out[n], carry in / out in the composite frame
 int launch_fir_hidec_demod(const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in, float *d_out,
                            long long n_out, float gain, const float2 *y_prev, float2 *y_last, const float *atan_tab,
-                           const float2 *etab, const float2 *vtab, hipStream_t st);
+                           const float2 *etab, const float2 *vtab, hipStream_t st, int n_streams = 1, long long x_stride = 0,
+                           long long d_stride = 0, long long n_lo = 0, int max_wg_per_cu = 0);
 int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in, float2 *y,
                      long long n_out, const float2 *gtab, hipStream_t st, const float2 *etab = nullptr,
                      const float2 *vtab = nullptr);

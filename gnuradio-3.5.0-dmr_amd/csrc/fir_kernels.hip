@@ -319,8 +319,12 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
                  int G, long long n_out, float2 *__restrict__ y, const float2 *__restrict__ gtab,
                  const float2 *__restrict__ etab, const float2 *__restrict__ vtab, long long ntiles,
                  float *__restrict__ d_out = nullptr, float gain = 0.f, const float2 *__restrict__ y_prev = nullptr,
-                 float2 *__restrict__ y_last = nullptr, const float *__restrict__ atan_tab = nullptr)
+                 float2 *__restrict__ y_last = nullptr, const float *__restrict__ atan_tab = nullptr,
+                 int n_streams = 1, long long x_stride = 0, long long d_stride = 0, long long n_lo = 0)
 {
+    // (DEMOD, batched: tile ids run over (tile, stream) pairs, streams fastest; stream s reads x + s x_stride, whose first
+    // n_lo items lie before the buffer and read as zero -- a fresh capture's history -- writes d_out + s d_stride and takes
+    // / leaves its carry at y_prev[s] / y_last[s])
     static_assert(!DEMOD || (PREMIX && !CTAPS), "the fused demodulator belongs to the pre-mix form");
     extern __shared__ __attribute__((aligned(16))) unsigned char hidec_smem[];
     typedef float hd_f32x2 __attribute__((ext_vector_type(2)));
@@ -356,15 +360,19 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
         v0c = hd_f32x2{a.x, a.y}; v1c = hd_f32x2{b.x, b.y};
     }
     // the stream: items >= n_in read as zero (and move no bytes)
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x), 0, (int)(n_in * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(gtab), 0, gtab ? (int)(n_out * 8) : 0, 0x00020000);
     hd_f32x2 pre[HIDEC_NR];
     hd_f32x4 gq{1.f, 0.f, 1.f, 0.f};
     const int TNEW = DEMOD ? Tn - 2 : Tn;            // new outputs per tile
-    auto request = [&](long long tile) __attribute__((always_inline)) {
+    auto request = [&](long long id) __attribute__((always_inline)) {
         int tq = t;
         asm volatile("" : "+v"(tq));                 // (offsets per tile: hoisted, they would be spilled)
-        const long long u0 = (tile * TNEW - (DEMOD ? 2 : 0)) * D;     // (DEMOD: the first tile starts two outputs early)
+        const long long tile = id / n_streams;
+        const int sidx = (int)(id - tile * n_streams);
+        // the stream from its first readable item on: items >= n_in read as zero (and move no bytes)
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x + (long long)sidx * x_stride + n_lo), 0,
+                                                                           (int)((n_in - n_lo) * 8), 0x00020000);
+        const long long u0 = (tile * TNEW - (DEMOD ? 2 : 0)) * D - n_lo;   // relative to the descriptor (DEMOD: the first tile starts two outputs early)
         const int first = u0 < 0 ? (int)-u0 : 0;     // samples before the stream: explicit out-of-range offsets
         const int vo = (int)(u0 * 8) + 8 * tq;
 #pragma unroll
@@ -382,8 +390,9 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
             gq = hd_f32x4{g0.x, g0.y, g1.x, g1.y};
         }
     };
-    long long tile = blockIdx.x;
-    if (tile < ntiles) request(tile);
+    long long id = blockIdx.x;
+    const long long nids = ntiles * n_streams;
+    if (id < nids) request(id);
     __syncthreads();                                 // taps visible
 
     // tap range of this lane's group: groups of NSUB taps, k over [0, ntaps + D)
@@ -392,7 +401,9 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
     const int gk0 = grp * gper, gk1 = idle ? gk0 : (gk0 + gper < ngroups ? gk0 + gper : ngroups);
     const hd_f32x2 *xl = xs + ((2 * tp * D) >> V1);  // 2 tp D is a multiple of 2P
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; id < nids; id += gridDim.x) {
+        const long long tile = id / n_streams;
+        const int sidx = (int)(id - tile * n_streams);
         // ---- registers -> LDS (pre-mixed)
 #pragma unroll
         for (int i = 0; i < HIDEC_NR; ++i) {
@@ -405,7 +416,7 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
         }
         const hd_f32x4 gcur = gq;
         __syncthreads();
-        if (tile + gridDim.x < ntiles) request(tile + gridDim.x);
+        if (id + gridDim.x < nids) request(id + gridDim.x);
 
         // ---- MACs: tap c[k] feeds the first output (k < ntaps), c[k-D] the second (k >= D); the tap table is zero padded
         // by D in front and behind (host), so no conditions are needed
@@ -457,7 +468,7 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
                     // tile's frame a_m = e^{+jw m D} y_bp (m = 1 for output -1); a fresh stream has none: zero
                     prev = make_float2(0.f, 0.f);
                     if (y_prev) {
-                        const float2 yp = y_prev[0], v1 = vtab[1];
+                        const float2 yp = y_prev[sidx], v1 = vtab[1];
                         prev = cmul_ref(yp, make_float2(v1.x, -v1.y));
                     }
                 }
@@ -466,16 +477,17 @@ fir_hidec_kernel(const float2 *__restrict__ x, long long n_in, const float *__re
                 const float d0 = quad_demod_fast(a0, prev, gain, tabv);
                 const float d1 = quad_demod_fast(a1, a0, gain, tabv);
                 if (tp > 0) {
-                    if (n + 1 < n_out && ((((uintptr_t)(d_out + n)) & 7) == 0)) {
-                        *reinterpret_cast<float2 *>(d_out + n) = make_float2(d0, d1);
+                    float *dst = d_out + (long long)sidx * d_stride;
+                    if (n + 1 < n_out && ((((uintptr_t)(dst + n)) & 7) == 0)) {
+                        *reinterpret_cast<float2 *>(dst + n) = make_float2(d0, d1);
                     } else {
-                        if (n < n_out) d_out[n] = d0;
-                        if (n + 1 < n_out) d_out[n + 1] = d1;
+                        if (n < n_out) dst[n] = d0;
+                        if (n + 1 < n_out) dst[n + 1] = d1;
                     }
                     // the call's last composite output, for the next call
                     if (y_last && (n == n_out - 1 || n + 1 == n_out - 1)) {
                         const bool second = n + 1 == n_out - 1;
-                        y_last[0] = cmul_ref(second ? a1 : a0, second ? make_float2(v1c.x, v1c.y) : make_float2(v0c.x, v0c.y));
+                        y_last[sidx] = cmul_ref(second ? a1 : a0, second ? make_float2(v1c.x, v1c.y) : make_float2(v0c.x, v0c.y));
                     }
                 }
             }
@@ -550,7 +562,8 @@ int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim,
 
 int launch_fir_hidec_demod(const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in, float *d_out,
                            long long n_out, float gain, const float2 *y_prev, float2 *y_last, const float *atan_tab,
-                           const float2 *etab, const float2 *vtab, hipStream_t st)
+                           const float2 *etab, const float2 *vtab, hipStream_t st, int n_streams, long long x_stride,
+                           long long d_stride, long long n_lo, int max_wg_per_cu)
 {
     if (n_out <= 0) return GRHIP_OK;
     if (!hidec_supported(decim, ntaps) || n_in < 1 || !etab || !vtab || !atan_tab)
@@ -565,9 +578,12 @@ int launch_fir_hidec_demod(const float *taps_padded, int ntaps, int decim, const
     int dev = 0, n_cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus < 1)
         n_cus = 256;
-    const long long per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
+    long long per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
+    if (max_wg_per_cu > 0 && per_cu > max_wg_per_cu) per_cu = max_wg_per_cu;
+    if (n_streams < 1 || n_lo < 0 || n_lo > n_in) return fail(GRHIP_EINVAL, "high-decimation FIR + demodulator: bad batch arguments");
     const long long cap = per_cu * n_cus;
-    const unsigned blocks = (unsigned)(ntiles < cap ? ntiles : cap);
+    const long long nids = ntiles * n_streams;
+    const unsigned blocks = (unsigned)(nids < cap ? nids : cap);
 #define GRHIP_HIDEC_D(V)                                                                                                \
     do {                                                                                                                \
         static size_t cfg = 0;                                                                                          \
@@ -576,7 +592,8 @@ int launch_fir_hidec_demod(const float *taps_padded, int ntaps, int decim, const
             cfg = lds;                                                                                                  \
         }                                                                                                               \
         hipLaunchKernelGGL((fir_hidec_kernel<false, V, true, true>), dim3(blocks), dim3(256), lds, st, x, n_in, taps_padded, ntaps, decim, \
-                           G, n_out, (float2 *)nullptr, (const float2 *)nullptr, etab, vtab, ntiles, d_out, gain, y_prev, y_last, atan_tab); \
+                           G, n_out, (float2 *)nullptr, (const float2 *)nullptr, etab, vtab, ntiles, d_out, gain, y_prev, y_last, atan_tab, \
+                           n_streams, x_stride, d_stride, n_lo);                                                        \
     } while (0)
     switch (v1) { case 1: GRHIP_HIDEC_D(1); break; case 2: GRHIP_HIDEC_D(2); break; case 3: GRHIP_HIDEC_D(3); break;
                   case 4: GRHIP_HIDEC_D(4); break; default: GRHIP_HIDEC_D(5); break; }

@@ -91,7 +91,7 @@ struct XlatingCore {
     bool demod_is_direct(int mode, bool demod, bool batched = false) const
     {
         if (demod && mode_matrix(mode) && use_mfma) return true;
-        if (demod && mode_fast(mode) && use_hidec && hidec_premix && !batched) return true;     // the direct kernel's fused demodulator
+        if (demod && mode_fast(mode) && use_hidec && hidec_premix) return true;     // the direct kernel's fused demodulator
         return demod && mode_fast(mode) && use_tiled && premix && (batched || !prefer_ols);
     }
     // d_in item 0 = input[0] of output 0 (oldest history item); items with index

@@ -555,6 +555,9 @@ GRHIP_API int grhip_pfb_channelizer_ccf_general_work_device(grhip_pfb_channelize
  * streams are independent units; this is the multi-stream batch that fills
  * the device for the serial M&M stage).  Each stream starts from fresh block
  * state on every run() (a capture is processed whole).
+ * Decimation 1 / 2 / 4 with any taps; every other decimation up to 256 with a
+ * real prototype (imaginary parts zero) of up to 1024 taps -- create fails with
+ * GRHIP_EINVAL for a shape no batched engine takes.
  * ====================================================================== */
 typedef struct grhip_dmr_chain grhip_dmr_chain;
 typedef struct grhip_dmr_chain_params {

@@ -105,6 +105,66 @@ def test_chain_three_streams_vs_oracle(gpu, po, wl):
             assert (out_ref & 2).sum() >= n // 4 // 10 // wl.CFG4["sync_period_syms"]     # sync words found
 
 
+@pytest.mark.parametrize("decim,ntaps,n_out", [(20, 400, 70_000), (10, 200, 100_000), (5, 200, 150_000), (3, 96, 40_000)])
+def test_chain_other_decimations(gpu, po, wl, decim, ntaps, n_out):
+    """the chain in front of a decimation the tiled / matrix-core kernels do not take (the direct kernel's batched demodulator
+    epilogue; 70 000 and more outputs: in time slices beside the clock recovery, 40 000: one slice): demodulator against the
+    oracle, every later stage bit-exact on what the stage before it produced, the planted sync words found in every mode
+    (demodulator gain and symbol clock rescaled to the new rate; at 2 samples per symbol, D = 20, the loop does not lock on
+    this signal and only the stage-by-stage checks apply)"""
+    import ctypes
+    torch = _torch()
+    c, c4 = wl.CFG2, wl.CFG4
+    S, n = 3, n_out * decim + decim - 1
+    proto = wl.lowpass_taps(ntaps, 100e3, 10e6).astype(np.complex64)
+    xs = [wl.fsk4_capture(n, stream_id=50 + s) for s in range(S)]
+    dev = torch.device("cuda", 0)
+    stride = n + 33
+    d_in = torch.zeros((S, stride, 2), dtype=torch.float32, device=dev)
+    for s in range(S):
+        d_in[s, :n] = torch.from_numpy(xs[s].view(np.float32).reshape(-1, 2))
+    d_bits = torch.zeros((S, n_out), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    omega = c4["omega"] * 4 / decim
+    gain = c["demod_gain"] * 4 / decim
+    ch = gpu.dmr_chain(decim, proto, c["center_freq"], c["fs"], gain, omega, c4["gain_omega"], c4["mu"],
+                       c4["gain_mu"], c4["omega_relative_limit"], wl.access_code_string(), c4["threshold"], S, n)
+    st = torch.cuda.Stream(device=dev)
+    results = {}
+    for mode in (gpu.MODE_FAST, gpu.MODE_GENERIC, gpu.MODE_FAST_VALU):
+        ch.set_mode(mode)
+        d_bits.zero_()
+        ch.run_device(d_in, n, stride, d_bits, n_out, d_n, st)
+        st.synchronize()
+        nb = d_n.cpu().numpy()
+        bits = d_bits.cpu().numpy()
+        p_dem, s_dem = ch.intermediate(0)
+        p_soft, s_soft = ch.intermediate(1)
+        for s in range(S):
+            dem_ref = po.chain_xlating_demod(decim, proto, c["center_freq"], c["fs"], gain, xs[s][: n_out * decim])
+            dem = np.empty(n_out, np.float32)
+            gpu.lib().grhip_memcpy_d2h(dem.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_dem + 4 * s * s_dem), n_out * 4)
+            if mode == gpu.MODE_GENERIC:
+                assert bits_equal(dem, dem_ref)
+            else:
+                ok, worst = demod_close(dem, dem_ref, gain=gain)
+                assert ok, (mode, s, worst)
+            soft_mine, _ = po.chain_mm(omega, c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], dem)
+            assert nb[s] == len(soft_mine)
+            soft = np.empty(nb[s], np.float32)
+            gpu.lib().grhip_memcpy_d2h(soft.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_soft + 4 * s * s_soft),
+                                       int(nb[s]) * 4)
+            assert bits_equal(soft, soft_mine)                      # the timing loop is exact on its input, sliced or not
+            mine = po.CorrelateAccessCode(wl.access_code_string(), c4["threshold"]).work(po.binary_slicer_fb(soft))
+            assert np.array_equal(bits[s, :nb[s]], mine)
+            results[(mode, s)] = bits[s, :nb[s]].copy()
+    if omega >= 4:
+        want = n // 40 // c4["sync_period_syms"]
+        assert want >= 1
+        for key, b in results.items():
+            assert want - 1 <= int(np.count_nonzero(b & 2)) <= want + 1, key
+
+
 def test_chain_properties_full_size(gpu, wl):
     """one 10 M-sample capture (BASELINE size): sync flags appear every
     sync_period symbols, streams are independent and runs are reproducible."""

@@ -402,6 +402,39 @@ def test_run_captures_batched_vs_oracle(gpu, po, wl, stride_pad, n):
             assert ok, (rep, s, worst)
 
 
+@pytest.mark.parametrize("decim,ntaps,stride_pad,n", [(20, 400, 0, 1_000_000), (5, 200, 63, 700_003), (3, 96, 1, 300_001),
+                                                      (8, 256, 7, 500_000)])
+def test_run_captures_other_decimations(gpu, po, wl, decim, ntaps, stride_pad, n):
+    """the batched launch at decimations only the direct kernel takes: (tile, stream) pairs walked by persistent workgroups,
+    the captures' zero history by range check, odd strides, lengths that are no multiple of the decimation"""
+    import torch
+    c = wl.CFG2
+    S = 3
+    proto = wl.lowpass_taps(ntaps, 100e3, 10e6).astype(np.complex64)
+    xs = [wl.fsk4_capture(n, stream_id=90 + s) for s in range(S)]
+    dev = torch.device("cuda", 0)
+    stride = n + stride_pad
+    d_in = torch.zeros((S * stride + 8, 2), dtype=torch.float32, device=dev)
+    for s in range(S):
+        d_in[s * stride: s * stride + n] = torch.from_numpy(xs[s].view(np.float32).reshape(-1, 2))
+    nout = n // decim
+    ostride = nout + 3
+    d_out = torch.zeros((S, ostride), dtype=torch.float32, device=dev)
+    blk = gpu.xlating_demod(decim, proto, c["center_freq"], c["fs"], 3.0)
+    st = torch.cuda.Stream(device=dev)
+    for mode in (gpu.MODE_FAST, gpu.MODE_FAST_VALU):
+        blk.set_mode(mode)
+        d_out.zero_()
+        blk.run_captures_device(S, n, d_in, stride, d_out, ostride, st)
+        st.synchronize()
+        got = d_out.cpu().numpy()
+        for s in range(S):
+            ref = po.chain_xlating_demod(decim, proto, c["center_freq"], c["fs"], 3.0, xs[s][: nout * decim])
+            ok, worst = demod_close(got[s, :nout], ref, gain=3.0)
+            assert ok, (mode, s, worst)
+            assert not got[s, nout:].any()
+
+
 @pytest.mark.parametrize("nout", [1, 5, 8, 9, 2015, 2016, 2017, 4033])
 def test_fused_xlating_demod_small_and_tile_edges(gpu, po, wl, nout):
     """output counts around the lane (8) and tile (2016 new outputs) granularity, two calls each

@@ -1,6 +1,7 @@
 """Secondary measurement (not the headline bench line): the full DMR chain
 (config 4/5 shape) over a batch of S captures on one GPU, per-kernel times via
-torch events.  usage: python tools/bench_chain.py [S] [n_samples]"""
+torch events.  usage: python tools/bench_chain.py [S] [n_samples] [decim ntaps]
+(decim / ntaps given: a low-pass of that length in front of that decimation, the symbol clock rescaled to the new rate)"""
 import json
 import os
 import sys
@@ -18,16 +19,19 @@ wl = g.workload
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 c, c4 = wl.CFG2, wl.CFG4
+decim = int(sys.argv[3]) if len(sys.argv) > 4 else c["decim"]
+proto = wl.lowpass_taps(int(sys.argv[4]), 100e3, 10e6).astype(np.complex64) if len(sys.argv) > 4 else wl.cfg2_proto_taps()
+omega = c4["omega"] * c["decim"] / decim
 dev = torch.device("cuda", 0)
 x = wl.fsk4_capture(n, stream_id=0)
 xt = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev)
 d_in = torch.empty((S, n, 2), dtype=torch.float32, device=dev)
 for s in range(S):
     d_in[s] = xt
-nout = n // 4
+nout = n // decim
 d_bits = torch.zeros((S, nout), dtype=torch.uint8, device=dev)
 d_n = torch.zeros(S, dtype=torch.int32, device=dev)
-ch = g.dmr_chain(c["decim"], wl.cfg2_proto_taps(), c["center_freq"], c["fs"], c["demod_gain"], c4["omega"],
+ch = g.dmr_chain(decim, proto, c["center_freq"], c["fs"], c["demod_gain"], omega,
                  c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], wl.access_code_string(),
                  c4["threshold"], S, n)
 st = torch.cuda.Stream(device=dev)
@@ -42,6 +46,6 @@ for _ in range(reps):
 e1.record(st)
 st.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(json.dumps({"workload": "full DMR chain (xlating+demod -> M&M -> slicer+correlator)", "streams": S,
-                  "samples_per_stream": n, "ms_per_batch": ms, "Msamples_per_s": S * n / ms / 1e3,
+print(json.dumps({"workload": "full DMR chain (xlating+demod -> M&M -> slicer+correlator)", "streams": S, "decim": decim,
+                  "ntaps": len(proto), "samples_per_stream": n, "ms_per_batch": ms, "Msamples_per_s": S * n / ms / 1e3,
                   "symbols": int(d_n[0].item())}))
