@@ -1053,6 +1053,11 @@ class dmr_chain(_Block):
     def set_mode(self, mode):
         _check(lib().grhip_dmr_chain_set_mode(self._h, int(mode)))
 
+    def set_captures_per_wave(self, captures):
+        L = lib()
+        L.grhip_dmr_chain_set_captures_per_wave.argtypes = [C.c_void_p, C.c_int]
+        _check(L.grhip_dmr_chain_set_captures_per_wave(self._h, int(captures)))
+
     def set_four_level(self, enable, pager_alpha=0.001):
         """4FSK tail: pager.slicer_fb(alpha) -> unpack_k_bits_bb(2) -> correlator; two output items per symbol"""
         L = lib()

@@ -39,6 +39,27 @@ struct grhip_dmr_chain : HandleBase {
 #ifndef GRHIP_CHAIN_WGCAP
 #define GRHIP_CHAIN_WGCAP 1
 #endif
+    // clock recovery with eight captures per wave (mm_rows_kernel): 2048 captures are 256 waves, one per SIMD of 64 CUs,
+    // and the FIR keeps two workgroups on each of the other CUs; from GRHIP_MM_ROWS_MIN captures on (below, one wave per
+    // capture has the shorter pass -- 0.145 against 0.2 us per symbol -- and there are SIMDs enough: 1536 captures run at
+    // 297-300 Gsamples/s that way and 261 this way, 2048 at 272 / 333-339, tools/gpu_chain_ab.sh)
+#ifndef GRHIP_MM_ROWS_MIN
+#define GRHIP_MM_ROWS_MIN 1792
+#endif
+#ifndef GRHIP_CHAIN_WGCAP_ROWS
+#define GRHIP_CHAIN_WGCAP_ROWS 0
+#endif
+    // ... and the two kernels get CUs of their own through two streams with CU masks: the loop's waves on GRHIP_MM_CUS CUs
+    // (mask bits go round the XCDs, so every XCD gives the same number), the FIR on the others.  On shared CUs the FIR's
+    // waves delay every pass of the loop (+40 %); a wave of the loop wants a SIMD to itself (2048 captures, same box:
+    // no masks 72.4 ms, 48 CUs 63.0, 56: 63.1, 64: 60.7, 96: 72.3 -- the FIR then lacks CUs)
+#ifndef GRHIP_MM_CUS
+#define GRHIP_MM_CUS 64
+#endif
+    hipStream_t st_mm8 = nullptr, st_fir8 = nullptr;
+    int fir8_cus = 0;
+    int captures_per_wave = 0;        // 0: by batch size; 1 / 8: forced (grhip_dmr_chain_set_captures_per_wave)
+    bool mm_rows() const { return captures_per_wave ? captures_per_wave == 8 : S >= GRHIP_MM_ROWS_MIN; }
     static constexpr int PIPE_CHUNKS = GRHIP_PIPE_CHUNKS;
     // 4FSK tail (grhip_dmr_chain_set_four_level): pager_slicer_fb -> unpack_k_bits(2) in front of the correlator
     bool four_level = false;
@@ -87,6 +108,20 @@ int grhip_dmr_chain_create(grhip_dmr_chain **h, const grhip_dmr_chain_params *p,
         rc = fail(GRHIP_EINVAL, "dmr_chain needs a decimation/tap count a batched FIR engine supports");
     if (!rc) {
         hipError_t e = hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking);
+        if (e == hipSuccess && GRHIP_MM_CUS > 0) {
+            int ncu = 0;
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+            if (ncu >= 4 * GRHIP_MM_CUS && ncu <= 1024) {
+                uint32_t m_mm[32] = {}, m_fir[32] = {};
+                for (int i = 0; i < ncu; ++i) (i < GRHIP_MM_CUS ? m_mm : m_fir)[i / 32] |= 1u << (i % 32);
+                const uint32_t words = (uint32_t)((ncu + 31) / 32);
+                if (hipExtStreamCreateWithCUMask(&c->st_mm8, words, m_mm) != hipSuccess) c->st_mm8 = nullptr;
+                if (c->st_mm8 && hipExtStreamCreateWithCUMask(&c->st_fir8, words, m_fir) != hipSuccess) c->st_fir8 = nullptr;
+                if (c->st_mm8 && !c->st_fir8) { (void)hipStreamDestroy(c->st_mm8); c->st_mm8 = nullptr; }
+                if (c->st_fir8) c->fir8_cus = ncu - GRHIP_MM_CUS;
+                (void)hipGetLastError();
+            }
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_end, hipEventDisableTiming);
         for (int i = 0; i < grhip_dmr_chain::PIPE_CHUNKS && e == hipSuccess; ++i)
@@ -120,6 +155,8 @@ void grhip_dmr_chain_destroy(grhip_dmr_chain *h)
     h->d_counts.release(); h->d_ystate.release(); h->d_corr.release(); h->d_scratch.release();
     h->d_sym.release(); h->d_dibits.release(); h->d_avg.release(); h->d_nbits2.release();
     if (h->st2) (void)hipStreamDestroy(h->st2);
+    if (h->st_mm8) (void)hipStreamDestroy(h->st_mm8);
+    if (h->st_fir8) (void)hipStreamDestroy(h->st_fir8);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     for (auto &e : h->ev_fir) if (e) (void)hipEventDestroy(e);
@@ -161,10 +198,17 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         const int NC = n_out >= 64 * 1024 ? grhip_dmr_chain::PIPE_CHUNKS : 1;
         const long long Lc = ((n_out + NC - 1) / NC + 63) / 64 * 64;       // slice length in outputs (rows stay 16-byte aligned)
         GRHIP_HIP(hipMemsetAsync(h->d_counts.p, 0, S * 2 * sizeof(int), st));
+        const int rows = h->mm_rows() ? 1 : 0;
+        // eight captures per wave: the loop and the FIR on CUs of their own (two masked streams)
+        const bool split = rows && NC > 1 && h->st_mm8 && h->st_fir8;
+        hipStream_t st_side = split ? h->st_mm8 : h->st2;
+        hipStream_t st_fir = split ? h->st_fir8 : st;
         GRHIP_HIP(hipEventRecord(h->ev_begin, st));
-        GRHIP_HIP(hipStreamWaitEvent(h->st2, h->ev_begin, 0));
-        st_mm = NC > 1 ? h->st2 : st;
-        h->core.mf_wg_cap = NC > 1 ? GRHIP_CHAIN_WGCAP : 0;
+        GRHIP_HIP(hipStreamWaitEvent(st_side, h->ev_begin, 0));
+        if (split) GRHIP_HIP(hipStreamWaitEvent(st_fir, h->ev_begin, 0));
+        st_mm = NC > 1 ? st_side : st;
+        h->core.mf_wg_cap = NC > 1 ? (rows ? GRHIP_CHAIN_WGCAP_ROWS : GRHIP_CHAIN_WGCAP) : 0;
+        h->core.mf_cu_cap = split ? h->fir8_cus : 0;
         for (int c = 0; c < NC; ++c) {
             const long long o0 = (long long)c * Lc;
             if (o0 >= n_out) break;
@@ -173,19 +217,20 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
             const float2 *yp = (c & 1) ? ys + S : ys;             // carry of the demodulator's previous sample
             float2 *yl = (c & 1) ? ys : ys + S;
             rc = h->core.run(h->mode, xc, hist + len * h->core.decim, len, nullptr, h->d_demod.as<float>() + o0,
-                             h->gain, yp, yl, h->tabs->atan_tab, st, h->S, (long long)stream_stride_items,
+                             h->gain, yp, yl, h->tabs->atan_tab, st_fir, h->S, (long long)stream_stride_items,
                              c == 0 ? hist : 0, (long long)h->out_stride);
-            if (rc) { h->core.mf_wg_cap = 0; return rc; }
+            if (rc) { h->core.mf_wg_cap = 0; h->core.mf_cu_cap = 0; return rc; }
             if (NC > 1) {
-                GRHIP_HIP(hipEventRecord(h->ev_fir[c], st));
-                GRHIP_HIP(hipStreamWaitEvent(h->st2, h->ev_fir[c], 0));
+                GRHIP_HIP(hipEventRecord(h->ev_fir[c], st_fir));
+                GRHIP_HIP(hipStreamWaitEvent(st_side, h->ev_fir[c], 0));
             }
             // 2) M&M clock recovery, one wavefront per stream, over what has been demodulated so far
             rc = launch_mm(h->d_mm.as<MMState>(), h->S, (int)n_out, (int)(o0 + len), h->d_demod.as<float>(),
                            (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
-                           h->d_counts.as<int>(), h->tabs->mmse_rev, st_mm, 1);
-            if (rc) { h->core.mf_wg_cap = 0; return rc; }
+                           h->d_counts.as<int>(), h->tabs->mmse_rev, st_mm, 1, rows);
+            if (rc) { h->core.mf_wg_cap = 0; h->core.mf_cu_cap = 0; return rc; }
         }
+        h->core.mf_cu_cap = 0;
         h->core.mf_wg_cap = 0;
     } else {
         // generic order: explicit zero history in a scratch row, one stream at a time
@@ -204,10 +249,13 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         // 2) M&M clock recovery, one wavefront per stream
         rc = launch_mm(h->d_mm.as<MMState>(), h->S, (int)n_out, (int)n_out, h->d_demod.as<float>(),
                        (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
-                       h->d_counts.as<int>(), h->tabs->mmse_rev, st);
+                       h->d_counts.as<int>(), h->tabs->mmse_rev, st, 0, h->mm_rows() ? 1 : 0);
         if (rc) return rc;
     }
 
+    // symbols a capture is expected to produce at most (the nominal clock and a margin): sizes the grids of the stages
+    // behind the clock recovery, which read the true counts on the device and walk longer streams in strides
+    const long long n_expect = (long long)((double)n_out / (double)h->mm_init.omega_mid * 1.125) + 4096;
     if (h->four_level) {
         // 3') 4FSK: DC-tracking four-level slicer, dibit unpack, correlator on the bit stream (2 items per symbol)
         GRHIP_HIP(hipMemsetAsync(h->d_avg.p, 0, S * sizeof(float), st_mm));                      // d_avg = 0 (pager_slicer_fb.cc:40)
@@ -221,7 +269,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         if (rc) return rc;
         rc = launch_correlate(h->cp, h->d_corr.as<CorrState>(), h->S, h->d_dibits.as<unsigned char>(), nullptr,
                               2 * (long long)h->out_stride, d_bits, (long long)bits_stride, 2 * n_out, h->d_nbits2.as<int>(), 1,
-                              st_mm);
+                              st_mm, 2 * n_expect);
         if (rc) return rc;
         GRHIP_HIP(hipMemcpyAsync(d_nbits, h->d_nbits2.p, S * sizeof(int), hipMemcpyDeviceToDevice, st_mm));
         if (st_mm != st) {
@@ -233,7 +281,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
     // 3) slicer + access-code correlator on the symbols each stream produced
     rc = launch_correlate(h->cp, h->d_corr.as<CorrState>(), h->S, nullptr, h->d_soft.as<float>(),
                           (long long)h->out_stride, d_bits, (long long)bits_stride, n_out,
-                          h->d_counts.as<int>(), 2, st_mm);
+                          h->d_counts.as<int>(), 2, st_mm, n_expect);
     if (rc) return rc;
     GRHIP_HIP(hipMemcpy2DAsync(d_nbits, sizeof(int), h->d_counts.p, 2 * sizeof(int), sizeof(int), S,
                                hipMemcpyDeviceToDevice, st_mm));
@@ -248,6 +296,13 @@ int grhip_dmr_chain_set_mode(grhip_dmr_chain *h, int mode)
 {
     if (!h || !mode_valid(mode)) return fail(GRHIP_EINVAL, "bad mode");
     h->mode = mode;
+    return GRHIP_OK;
+}
+
+int grhip_dmr_chain_set_captures_per_wave(grhip_dmr_chain *h, int captures)
+{
+    if (!h || !(captures == 0 || captures == 1 || captures == 8)) return fail(GRHIP_EINVAL, "captures per wave: 0 (by batch size), 1 or 8");
+    h->captures_per_wave = captures;
     return GRHIP_OK;
 }
 

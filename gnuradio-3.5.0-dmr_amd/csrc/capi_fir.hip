@@ -369,6 +369,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         a.vec_store = demod ? ((o & 7) == 0 && !(out_stride & 1)) : ((o & 15) == 0 && !(out_stride & 1));
         a.sched = mf_sched.get();
         a.max_wg_per_cu = mf_wg_cap;
+        a.max_cus = mf_cu_cap;
         rc = launch_fir_mfma(decim, ntaps, true, demod ? EPI_DEMOD : EPI_ROTATE, a, st);
         if (rc) return rc;
         pos += n_out;
@@ -377,7 +378,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
     if (hidec_direct) {
         rc = launch_fir_hidec_demod(d_hidec_taps.as<float>(), ntaps, decim, d_in, batched ? n_in : (n_out - 1) * decim + ntaps,
                                     d_demod, n_out, gain, y_prev, y_last, atan_tab, d_hidec_etab.as<float2>(),
-                                    d_hidec_vtab.as<float2>(), st, n_streams, x_stride, out_stride, n_lo, mf_wg_cap);
+                                    d_hidec_vtab.as<float2>(), st, n_streams, x_stride, out_stride, n_lo, mf_wg_cap, mf_cu_cap);
         if (rc) return rc;
         pos += n_out;
         return GRHIP_OK;

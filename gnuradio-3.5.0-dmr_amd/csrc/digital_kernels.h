@@ -17,9 +17,10 @@ struct MMState {
 // state[s], counts[2*s] = produced, counts[2*s+1] = consumed.
 // resume != 0: counts[] hold the stream's totals so far, the call continues from there with
 // noutput_items / ninput_items counted from the stream's start (see mm_kernel).
+// rows != 0: eight streams per wave (mm_rows_kernel; 16-byte aligned rows with 3 floats of slack behind ninput_items).
 int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items, const float *in,
               long long in_stride, float *out, long long out_stride, int *counts,
-              const float *mmse_rev, hipStream_t st, int resume = 0);
+              const float *mmse_rev, hipStream_t st, int resume = 0, int rows = 0);
 
 int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipStream_t st);
 // pager_slicer_fb: d_avg[s] carried in device memory; streams s at in + s*in_stride / out + s*out_stride
@@ -49,6 +50,6 @@ struct CorrParams {
 // count on the device (n = min(n, n_ptr[s*n_ptr_stride])).
 int launch_correlate(const CorrParams &p, CorrState *state, int n_streams, const unsigned char *in_bytes,
                      const float *in_soft, long long in_stride, unsigned char *out, long long out_stride,
-                     long long n, const int *n_ptr, int n_ptr_stride, hipStream_t st);
+                     long long n, const int *n_ptr, int n_ptr_stride, hipStream_t st, long long n_expect = 0);
 
 }  // namespace grhip

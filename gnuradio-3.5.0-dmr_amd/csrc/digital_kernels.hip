@@ -66,10 +66,12 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
         oo0 = __builtin_amdgcn_readfirstlane(counts[2 * s]);
         ii0 = __builtin_amdgcn_readfirstlane(counts[2 * s + 1]);
     }
-    const float *__restrict__ x = in + (long long)s * in_stride + ii0;
+    // (sample positions count from the stream's start in every launch: a loop that steps back behind the point a resumed
+    // launch started from goes on as it would in one launch, and a stream that has stepped before its first sample -- where
+    // the reference would read before its buffer -- stays ended)
+    const float *__restrict__ x = in + (long long)s * in_stride;
     float *__restrict__ y = out + (long long)s * out_stride + oo0;
     noutput_items -= oo0;
-    ninput_items -= ii0;
 
     for (int i = lane; i < MM_NTAPS * (MM_NSTEPS + 1); i += 64) s_taps[i] = mmse_rev[i];
 
@@ -77,14 +79,14 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
     float mu = st.mu, omega = st.omega, last = st.last_sample;          // identical in every lane
     const float omega_mid = st.omega_mid, gain_omega = st.gain_omega, gain_mu = st.gain_mu;
     const float rel = st.omega_relative_limit;
-    int ii = 0, oo = 0;                               // wave-uniform (kept in SGPRs)
+    int ii = ii0, oo = 0;                             // wave-uniform (kept in SGPRs)
     const int ni = ninput_items - MM_NTAPS;           // .cc:113
     const int k = lane & 7;                           // this lane's tap of the interpolator
     const float *tapcol = &s_taps[k * (MM_NSTEPS + 1)];
     // interpolate(&in[ii], d_mu): imu = (int) rint(mu * NSTEPS)   (gri_mmse_fir_interpolator.cc:64)
     int imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
     imu = imu < 0 ? 0 : (imu > MM_NSTEPS ? MM_NSTEPS : imu);
-    bool done = !(oo < noutput_items && ii < ni);
+    bool done = !(oo < noutput_items && ii < ni) || ii < 0;
 
     while (!done) {
         const int base = ii;
@@ -153,15 +155,185 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
         so.mu = mu; so.omega = omega; so.last_sample = last;
         state[s] = so;
         counts[2 * s + 0] = oo0 + oo;
-        counts[2 * s + 1] = ii0 + ii;          // consume_each(ii)
+        counts[2 * s + 1] = ii;                // consume_each(ii)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// mm_rows_kernel: EIGHT captures per wavefront, one per group of 8 lanes (the chain's big batches).
+// The recurrence of one capture occupies 8 lanes (one tap product each) and a lone wave issues an instruction every
+// 4-5 cycles whatever its lanes hold, so the seven other groups of mm_kernel's wave repeated the same work: here each
+// group of 8 lanes runs its own capture -- same instructions, same order of the float operations (bit-exact), eight
+// symbols per pass.  What was wave-uniform scalar state (sample position, counts) is group-uniform vector state; a
+// group that has to wait (window exhausted) or has finished is masked.
+//  * samples: a ring of 256 floats per capture in LDS (8 KB per wave + the 4 KB tap table: one such wave fits beside two
+//    FIR workgroups on a CU), topped up 128 at a time; the next 128 are requested into registers as soon as the previous
+//    chunk is accepted, so a top-up is an LDS write; a group accepts a chunk once it has left the older half of its
+//    ring, and every group that can accepts when any group must (the wave leaves the symbol loop at most once per
+//    128/omega symbols); a position outside the ring (a jump of the loop) re-seeds the ring there;
+//  * the 8-tap sum is formed with the same DPP row shifts (the two groups of a 16-lane row do not meet in the lanes that
+//    count), the result goes to the group's lanes with a quad broadcast and a masked row shift;
+//  * outputs collect in one register per lane, a group stores 8 symbols (32 bytes) at a time.
+// in / out are indexed from the stream's start (resume != 0: counts[] hold what has been produced / consumed so far);
+// the caller guarantees 16-byte aligned rows with at least 3 floats of slack behind ninput_items (the chain's rows).
+// ---------------------------------------------------------------------------
+constexpr int MMR_RL = 8, MMR_ROWS = 64 / MMR_RL;
+constexpr int MMR_RING = 256, MMR_CHUNK = 128;
+
+__global__ void __launch_bounds__(64)
+mm_rows_kernel(MMState *__restrict__ state, int n_streams, int noutput_items, int ninput_items,
+               const float *__restrict__ in, long long in_stride, float *__restrict__ out, long long out_stride,
+               int *__restrict__ counts, const float *__restrict__ mmse_rev, int resume)
+{
+    __shared__ __attribute__((aligned(16))) float s_ring[MMR_ROWS * MMR_RING];
+    __shared__ float s_taps[MM_NTAPS * (MM_NSTEPS + 1)];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+
+    const int lane = threadIdx.x, row = lane / MMR_RL, l = lane % MMR_RL;
+    const int s = blockIdx.x * MMR_ROWS + row;
+    const bool valid = s < n_streams;
+    const int sc = valid ? s : n_streams - 1;
+    __builtin_amdgcn_s_setprio(3);
+    for (int i = lane; i < MM_NTAPS * (MM_NSTEPS + 1); i += 64) s_taps[i] = mmse_rev[i];
+
+    int oo = 0, ii = 0;                               // produced (stored) / consumed so far, from the stream's start
+    if (resume) { oo = counts[2 * sc]; ii = counts[2 * sc + 1]; }
+    const float *__restrict__ x = in + (long long)sc * in_stride;
+    float *__restrict__ y = out + (long long)sc * out_stride;
+    const MMState st = state[sc];
+    float mu = st.mu, omega = st.omega, last = st.last_sample;          // identical in the lanes of a group
+    const float omega_mid = st.omega_mid, gain_omega = st.gain_omega, gain_mu = st.gain_mu;
+    const float rel = st.omega_relative_limit;
+    const int ni = ninput_items - MM_NTAPS;           // .cc:113
+    const float *tapcol = &s_taps[l * (MM_NSTEPS + 1)];
+    float *ring = &s_ring[row * MMR_RING];
+    int imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
+    imu = imu < 0 ? 0 : (imu > MM_NSTEPS ? MM_NSTEPS : imu);
+    bool fin = !valid || !(oo < noutput_items && ii < ni) || ii < 0;
+    int lo = 0, hi = 0;                               // the ring holds samples [lo, hi)
+    f4 pf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pf[q] = f4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_chunk = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = h + 32 * q + 4 * l;
+            pf[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (g < ninput_items) pf[q] = *reinterpret_cast<const f4 *>(x + g);
+        }
+    };
+    if (!fin) {
+        lo = hi = ii & ~(MMR_CHUNK - 1);
+        load_chunk(hi);
+    }
+    __syncthreads();                                  // tap table
+
+    for (;;) {
+        // ---- top-up: every group that has left the older half of its ring takes the chunk it has requested
+        if (!fin) {
+            if (ii < lo || ii >= hi + MMR_CHUNK) {    // outside the ring and the requested chunk: start again there
+                lo = hi = ii & ~(MMR_CHUNK - 1);
+                load_chunk(hi);
+            }
+            if (ii >= hi - MMR_CHUNK) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f4 *>(&ring[(hi + 32 * q + 4 * l) & (MMR_RING - 1)]) = pf[q];
+                hi += MMR_CHUNK;
+                lo = lo > hi - MMR_RING ? lo : hi - MMR_RING;
+                load_chunk(hi);
+            }
+        }
+        __syncthreads();                              // (one wave: orders the ring writes before the reads below)
+        // a symbol may start at ii in [lo, min(hi - 8, ni - 1)]: ONE unsigned compare per symbol
+        const int lim = hi - MM_NTAPS < ni - 1 ? hi - MM_NTAPS : ni - 1;
+        const unsigned span = (unsigned)(lim - lo);
+        const bool act = !fin && lim >= lo && (unsigned)(ii - lo) <= span;
+        if (!__any(act)) {
+            if (!__any(!fin)) break;
+            continue;
+        }
+        // every active group takes a symbol per pass, so the count of symbols waiting in obuf is wave-uniform; groups of
+        // 8 (one store per group), single symbols while some capture is within 8 outputs of its limit
+        const int K = __any(act && noutput_items - oo < MMR_RL) ? 1 : MMR_RL;
+        if (act) {
+            float obuf = 0.f;
+            // one symbol of every active group; returns whether all of them may go on (wave-uniform)
+            auto step = [&](int c) __attribute__((always_inline)) -> bool {
+                // lanes 0..7 of the group: (0 + tap k * sample k), see mm_kernel
+                const float p = __builtin_fmaf(tapcol[imu], ring[(ii + l) & (MMR_RING - 1)], 0.0f);
+                const float acc = p + row_shl<4>(p);                          // lanes 0..3 of the group: acc_j
+                float o = acc + row_shl<1>(acc);
+                o = o + row_shl<2>(acc);
+                o = o + row_shl<3>(acc);                                      // lane 0 of the group
+                // to the 8 lanes of the group: lane 0 of every quad to its quad, then quads 0 / 2 to quads 1 / 3
+                int ob = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o), 0x00, 0xf, 0xf, true);
+                ob = __builtin_amdgcn_update_dpp(ob, ob, 0x114, 0xf, 0xa, false);
+                obuf = l == c ? __builtin_bit_cast(float, ob) : obuf;
+                const unsigned ou = (unsigned)ob, lb = __builtin_bit_cast(unsigned, last);
+                const float t1 = __builtin_bit_cast(float, ou ^ (lb & 0x80000000u));     // slice(last) * o
+                const float t2 = __builtin_bit_cast(float, lb ^ (ou & 0x80000000u));     // slice(o) * last
+                const float mm_val = t1 - t2;                                     // .cc:120
+                last = __builtin_bit_cast(float, ob);
+                omega = omega + gain_omega * mm_val;                              // .cc:123
+                omega = omega_mid + branchless_clip(omega - omega_mid, rel);      // .cc:124
+                mu = mu + omega + gain_mu * mm_val;                               // .cc:125
+                const float fl = __builtin_floorf(mu);
+                ii += (int)fl;                                                    // .cc:127
+                mu = mu - fl;                                                     // .cc:128
+                imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
+                return __all((unsigned)(ii - lo) <= span);
+            };
+            bool inw = true;
+            do {
+                int c = 1;                            // symbols in obuf after the passes below (wave-uniform)
+                if (K == 1) {
+                    inw = step(0);
+                } else {
+                    // (unrolled: the lane that keeps symbol c is a constant mask, the pass count no loop variable)
+                    do {
+                        inw = step(0); if (!inw) break; ++c;
+                        inw = step(1); if (!inw) break; ++c;
+                        inw = step(2); if (!inw) break; ++c;
+                        inw = step(3); if (!inw) break; ++c;
+                        inw = step(4); if (!inw) break; ++c;
+                        inw = step(5); if (!inw) break; ++c;
+                        inw = step(6); if (!inw) break; ++c;
+                        inw = step(7);
+                    } while (false);
+                }
+                if (l < c) y[oo + l] = obuf;
+                oo += c;
+                if (!(oo < noutput_items)) { fin = true; inw = false; }
+                inw = __all(inw);
+            } while (inw);
+            // left the ring, or the stream: .cc:113 (ii < ni), and the reference would read before its buffer at ii < 0
+            if (!(ii < ni) || ii < 0) fin = true;
+        }
+    }
+    if (valid && l == 0) {
+        MMState so = st;
+        so.mu = mu; so.omega = omega; so.last_sample = last;
+        state[s] = so;
+        counts[2 * s + 0] = oo;
+        counts[2 * s + 1] = ii;                       // consume_each(ii)
     }
 }
 
 int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items, const float *in,
               long long in_stride, float *out, long long out_stride, int *counts, const float *mmse_rev,
-              hipStream_t st, int resume)
+              hipStream_t st, int resume, int rows)
 {
     if (n_streams <= 0) return GRHIP_OK;
+    if (rows) {
+        if ((((uintptr_t)in) & 15) || (in_stride & 3))
+            return fail(GRHIP_EINVAL, "clock recovery, eight captures per wave: rows must be 16-byte aligned");
+        hipLaunchKernelGGL(mm_rows_kernel, dim3((n_streams + MMR_ROWS - 1) / MMR_ROWS), dim3(64), 0, st, state, n_streams,
+                           noutput_items, ninput_items, in, in_stride, out, out_stride, counts, mmse_rev, resume);
+        GRHIP_HIP(hipGetLastError());
+        return GRHIP_OK;
+    }
     hipLaunchKernelGGL(mm_kernel, dim3(n_streams), dim3(64), 0, st, state, noutput_items, ninput_items, in,
                        in_stride, out, out_stride, counts, mmse_rev, resume);
     GRHIP_HIP(hipGetLastError());
@@ -372,8 +544,7 @@ corr_kernel(CorrParams p, const CorrState *__restrict__ state_in, const unsigned
     const int s = blockIdx.y, t = threadIdx.x;
     long long n = n_arg;
     if (n_ptr) { long long m = n_ptr[(long long)s * n_ptr_stride]; n = m < n ? m : n; }
-    const long long tile0 = (long long)blockIdx.x * CORR_TPW;
-    if (tile0 * CORR_TB >= n) return;
+    if ((long long)blockIdx.x * CORR_TPW * CORR_TB >= n) return;
     const unsigned char *__restrict__ xb = !SOFT ? in_bytes + (long long)s * in_stride : nullptr;
     const float *__restrict__ xf = SOFT ? in_soft + (long long)s * in_stride : nullptr;
     const CorrState st = state_in[s];
@@ -413,6 +584,9 @@ corr_kernel(CorrParams p, const CorrState *__restrict__ state_in, const unsigned
             }
         }
     };
+    // (the grid may be smaller than the stream -- the launcher sizes it by the expected item count: a workgroup goes on
+    // in strides of the grid)
+    for (long long tile0 = (long long)blockIdx.x * CORR_TPW; tile0 * CORR_TB < n; tile0 += (long long)gridDim.x * CORR_TPW) {
     bool wide = is_wide(tile0 * CORR_TB);
     if (wide) request(tile0 * CORR_TB);
 
@@ -522,6 +696,7 @@ corr_kernel(CorrParams p, const CorrState *__restrict__ state_in, const unsigned
         }
         __syncthreads();            // P belongs to the next tile from here
     }
+    }
 }
 
 // registers after n items (one 64-lane workgroup per stream)
@@ -575,11 +750,14 @@ corr_tail_kernel(CorrParams p, CorrState *__restrict__ state, const unsigned cha
 
 int launch_correlate(const CorrParams &p, CorrState *state, int n_streams, const unsigned char *in_bytes,
                      const float *in_soft, long long in_stride, unsigned char *out, long long out_stride,
-                     long long n, const int *n_ptr, int n_ptr_stride, hipStream_t st)
+                     long long n, const int *n_ptr, int n_ptr_stride, hipStream_t st, long long n_expect)
 {
     if (n <= 0 || n_streams <= 0) return GRHIP_OK;
     const long long per_wg = (long long)CORR_TB * CORR_TPW;
-    dim3 grid((unsigned)((n + per_wg - 1) / per_wg), (unsigned)n_streams);
+    // n is a capacity when n_ptr gives the streams' item counts: the grid covers what is expected (workgroups past a
+    // stream's count leave at once, but a million of them cost milliseconds), longer streams are walked in strides
+    const long long n_grid = n_expect > 0 && n_expect < n ? n_expect : n;
+    dim3 grid((unsigned)((n_grid + per_wg - 1) / per_wg), (unsigned)n_streams);
     if (in_bytes) hipLaunchKernelGGL(corr_kernel<false>, grid, dim3(256), 0, st, p, (const CorrState *)state, in_bytes, in_soft,
                                      in_stride, out, out_stride, n, n_ptr, n_ptr_stride);
     else hipLaunchKernelGGL(corr_kernel<true>, grid, dim3(256), 0, st, p, (const CorrState *)state, in_bytes, in_soft,

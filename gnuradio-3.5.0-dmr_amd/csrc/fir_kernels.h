@@ -90,6 +90,7 @@ struct FirMfmaArgs {
     int vec_store;          // (unused: outputs go through buffer stores, dword alignment suffices)
     unsigned *sched;        // tile queue counters (as FirTiledArgs::sched), or null
     int max_wg_per_cu;      // 0: as many as fit (2); 1: leave half of every CU to a kernel running beside this one
+    int max_cus;            // 0: the device's; else the CUs the stream may use (a stream with a CU mask)
 };
 bool mfma_supported(int decim, int ntaps);
 int launch_fir_mfma(int decim, int ntaps, bool premix, int epi, const FirMfmaArgs &a, hipStream_t st);
@@ -106,7 +107,7 @@ void hidec_premix_tables(double omega, int decim, std::vector<float> &etab, std:
 int launch_fir_hidec_demod(const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in, float *d_out,
                            long long n_out, float gain, const float2 *y_prev, float2 *y_last, const float *atan_tab,
                            const float2 *etab, const float2 *vtab, hipStream_t st, int n_streams = 1, long long x_stride = 0,
-                           long long d_stride = 0, long long n_lo = 0, int max_wg_per_cu = 0);
+                           long long d_stride = 0, long long n_lo = 0, int max_wg_per_cu = 0, int max_cus = 0);
 int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in, float2 *y,
                      long long n_out, const float2 *gtab, hipStream_t st, const float2 *etab = nullptr,
                      const float2 *vtab = nullptr);

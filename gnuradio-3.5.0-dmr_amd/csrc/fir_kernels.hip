@@ -563,7 +563,7 @@ int launch_fir_hidec(bool ctaps, const float *taps_padded, int ntaps, int decim,
 int launch_fir_hidec_demod(const float *taps_padded, int ntaps, int decim, const float2 *x, long long n_in, float *d_out,
                            long long n_out, float gain, const float2 *y_prev, float2 *y_last, const float *atan_tab,
                            const float2 *etab, const float2 *vtab, hipStream_t st, int n_streams, long long x_stride,
-                           long long d_stride, long long n_lo, int max_wg_per_cu)
+                           long long d_stride, long long n_lo, int max_wg_per_cu, int max_cus)
 {
     if (n_out <= 0) return GRHIP_OK;
     if (!hidec_supported(decim, ntaps) || n_in < 1 || !etab || !vtab || !atan_tab)
@@ -581,7 +581,7 @@ int launch_fir_hidec_demod(const float *taps_padded, int ntaps, int decim, const
     long long per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
     if (max_wg_per_cu > 0 && per_cu > max_wg_per_cu) per_cu = max_wg_per_cu;
     if (n_streams < 1 || n_lo < 0 || n_lo > n_in) return fail(GRHIP_EINVAL, "high-decimation FIR + demodulator: bad batch arguments");
-    const long long cap = per_cu * n_cus;
+    const long long cap = per_cu * (max_cus > 0 && max_cus < n_cus ? max_cus : n_cus);
     const long long nids = ntiles * n_streams;
     const unsigned blocks = (unsigned)(nids < cap ? nids : cap);
 #define GRHIP_HIDEC_D(V)                                                                                                \

@@ -584,7 +584,7 @@ static int launch_mfma_inst(const FirMfmaArgs &a, hipStream_t st)
     if (wgs > 2) wgs = 2;
     if (a.max_wg_per_cu > 0 && wgs > a.max_wg_per_cu) wgs = a.max_wg_per_cu;
     if (wgs < 1) wgs = 1;
-    long long grid = (long long)wgs * g_mf_cus;
+    long long grid = (long long)wgs * (a.max_cus > 0 && a.max_cus < g_mf_cus ? a.max_cus : g_mf_cus);
     if (grid > tiles) grid = tiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(mf::THREADS), G::LDS, st, a);
     GRHIP_HIP(hipGetLastError());

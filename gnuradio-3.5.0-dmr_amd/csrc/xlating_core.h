@@ -48,6 +48,7 @@ struct XlatingCore {
     float mf_wstep[2] = {1.f, 0.f};
     DevBuf d_mf_A[2], d_mf_wlane[2], d_mf_stab, d_mf_vtab;     // [alignment parity]
     SchedBuf mf_sched;
+    int mf_cu_cap = 0;                          // FirMfmaArgs::max_cus of the next launches (the chain's masked FIR stream)
     int mf_wg_cap = 0;                          // FirMfmaArgs::max_wg_per_cu of the next launches (the chain's pipeline sets 1)
     DevBuf scratch_y;
     SchedBuf sched;                             // tile queue of the tiled kernel (one launch at a time per handle)

@@ -578,6 +578,11 @@ GRHIP_API void grhip_dmr_chain_destroy(grhip_dmr_chain *h);
  * stream at a time): the whole chain is then bit-exact against the reference's
  * generic path, symbols and bit decisions included. */
 GRHIP_API int grhip_dmr_chain_set_mode(grhip_dmr_chain *h, int mode);
+/* Scheduling of the clock recovery (digital_clock_recovery_mm_ff.cc:116-134, a serial recurrence per capture): one
+ * wavefront per capture (1), or eight captures per wavefront (8: the shape for batches of more than a thousand
+ * captures, where the loop then leaves the FIR its full grid); 0 = chosen by n_streams (the default).  Results are
+ * identical (both forms are bit-exact on their input). */
+GRHIP_API int grhip_dmr_chain_set_captures_per_wave(grhip_dmr_chain *h, int captures);
 /* 4FSK tail: with enable != 0 the symbols go through pager_slicer_fb(alpha)
  * (gr-pager/lib/pager_slicer_fb.cc:47-84) -> gr_unpack_k_bits_bb(2) (general/gr_unpack_k_bits_bb.cc:64-69) ->
  * the access-code correlator instead of the binary slicer: both bits of every symbol, most significant first.

@@ -165,6 +165,138 @@ def test_chain_other_decimations(gpu, po, wl, decim, ntaps, n_out):
             assert want - 1 <= int(np.count_nonzero(b & 2)) <= want + 1, key
 
 
+@pytest.mark.parametrize("decim,ntaps,n_out,omega", [(4, 256, 175_000, 10.0), (20, 400, 70_000, 2.0), (4, 256, 90_000, 37.3),
+                                                     (4, 256, 66_000, 150.7), (4, 256, 40_000, 10.0)])
+def test_chain_eight_captures_per_wave(gpu, po, wl, decim, ntaps, n_out, omega):
+    """the clock recovery with eight captures per wavefront (the shape of batches beyond a thousand captures, forced here on
+    11 captures: one full wave and one with three of its eight groups in use): bit-exact on its input like the one-capture
+    form, and the two forms produce identical chains.  Symbol clocks from 2 to 150 samples per symbol: many symbols per
+    ring top-up, few, and (150 > the ring's chunk) a ring re-seeded at every symbol; time-sliced and single-slice runs."""
+    import ctypes
+    torch = _torch()
+    c, c4 = wl.CFG2, wl.CFG4
+    S, n = 11, n_out * decim + 1
+    proto = wl.cfg2_proto_taps() if decim == 4 else wl.lowpass_taps(ntaps, 100e3, 10e6).astype(np.complex64)
+    gain = c["demod_gain"] * 4 / decim
+    xs = [wl.fsk4_capture(n, stream_id=60 + s) for s in range(S)]
+    dev = torch.device("cuda", 0)
+    stride = n + 7
+    d_in = torch.zeros((S, stride, 2), dtype=torch.float32, device=dev)
+    for s in range(S):
+        d_in[s, :n] = torch.from_numpy(xs[s].view(np.float32).reshape(-1, 2))
+    d_bits = torch.zeros((S, n_out), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    ch = gpu.dmr_chain(decim, proto, c["center_freq"], c["fs"], gain, omega, c4["gain_omega"], c4["mu"], c4["gain_mu"],
+                       c4["omega_relative_limit"], wl.access_code_string(), c4["threshold"], S, n)
+    st = torch.cuda.Stream(device=dev)
+    for mode in (gpu.MODE_FAST, gpu.MODE_GENERIC):
+        ch.set_mode(mode)
+        got = {}
+        for cpw in (8, 1):
+            ch.set_captures_per_wave(cpw)
+            d_bits.zero_(); d_n.zero_()
+            torch.cuda.synchronize()
+            ch.run_device(d_in, n, stride, d_bits, n_out, d_n, st)
+            st.synchronize()
+            nb = d_n.cpu().numpy()
+            bits = d_bits.cpu().numpy()
+            p_dem, s_dem = ch.intermediate(0)
+            p_soft, s_soft = ch.intermediate(1)
+            softs = []
+            for s in range(S):
+                dem = np.empty(n_out, np.float32)
+                gpu.lib().grhip_memcpy_d2h(dem.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_dem + 4 * s * s_dem), n_out * 4)
+                soft = np.empty(nb[s], np.float32)
+                gpu.lib().grhip_memcpy_d2h(soft.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_soft + 4 * s * s_soft),
+                                           int(nb[s]) * 4)
+                if cpw == 8:
+                    ref, _ = po.chain_mm(omega, c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], dem)
+                    assert nb[s] == len(ref), (mode, s)
+                    assert bits_equal(soft, ref), (mode, s)
+                    mine = po.CorrelateAccessCode(wl.access_code_string(), c4["threshold"]).work(po.binary_slicer_fb(soft))
+                    assert np.array_equal(bits[s, :nb[s]], mine)
+                softs.append((soft, bits[s, :nb[s]].copy()))
+            got[cpw] = softs
+        for s in range(S):
+            assert bits_equal(got[8][s][0], got[1][s][0]) and np.array_equal(got[8][s][1], got[1][s][1]), (mode, s)
+    # the 4FSK tail behind it (reads the symbol counts the clock recovery leaves)
+    ch.set_mode(gpu.MODE_FAST)
+    ch.set_four_level(True, 0.01)
+    d_bits2 = torch.zeros((S, 2 * n_out), dtype=torch.uint8, device=dev)
+    outs = {}
+    for cpw in (8, 1):
+        ch.set_captures_per_wave(cpw)
+        d_bits2.zero_()
+        torch.cuda.synchronize()
+        ch.run_device(d_in, n, stride, d_bits2, 2 * n_out, d_n, st)
+        st.synchronize()
+        outs[cpw] = (d_n.cpu().numpy().copy(), d_bits2.cpu().numpy().copy())
+    assert np.array_equal(outs[8][0], outs[1][0]) and np.array_equal(outs[8][1], outs[1][1])
+
+
+def test_chain_more_symbols_than_the_nominal_clock_gives(gpu, po, wl):
+    """the stages behind the clock recovery size their grids by the nominal symbol count (+ 12.5 %) and walk longer streams
+    in strides: a 2-samples-per-symbol loop allowed to go down to 1.1 (the limit is absolute: digital_clock_recovery_mm_ff.cc:124),
+    on a frequency waveform that makes every timing error negative (pulses decaying to zero with alternating sign), settles
+    there and produces 1.2 times the nominal count -- every symbol is still sliced and correlated (both clock-recovery
+    forms, binary and 4-level tails)"""
+    import ctypes
+    torch = _torch()
+    c, c4 = wl.CFG2, wl.CFG4
+    S, n_out = 3, 800_000
+    n = n_out * 4
+    xs = []
+    for s in range(S):
+        P = 400 + 40 * s
+        t = np.arange(n)
+        saw = (1.0 - (t % P) / P) * np.where((t // P) % 2 == 0, 1.0, -1.0)
+        ph = 2 * np.pi * np.cumsum(c["center_freq"] + 30e3 * saw) / c["fs"]
+        xs.append(np.exp(1j * ph).astype(np.complex64))
+    dev = torch.device("cuda", 0)
+    d_in = torch.zeros((S, n, 2), dtype=torch.float32, device=dev)
+    for s in range(S):
+        d_in[s] = torch.from_numpy(xs[s].view(np.float32).reshape(-1, 2))
+    d_bits = torch.zeros((S, 2 * n_out), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    omega, g_omega, g_mu, rel = 2.0, 0.1, 0.01, 0.9
+    ch = gpu.dmr_chain(4, wl.cfg2_proto_taps(), c["center_freq"], c["fs"], c["demod_gain"], omega, g_omega, c4["mu"], g_mu, rel,
+                       wl.access_code_string(), c4["threshold"], S, n)
+    st = torch.cuda.Stream(device=dev)
+    longest = 0
+    for cpw in (1, 8):
+        ch.set_captures_per_wave(cpw)
+        ch.set_four_level(False, 0.0)
+        d_bits.zero_()
+        torch.cuda.synchronize()
+        ch.run_device(d_in, n, n, d_bits, 2 * n_out, d_n, st)
+        st.synchronize()
+        nb = d_n.cpu().numpy()
+        bits = d_bits.cpu().numpy()
+        p_soft, s_soft = ch.intermediate(1)
+        softs = []
+        for s in range(S):
+            soft = np.empty(nb[s], np.float32)
+            gpu.lib().grhip_memcpy_d2h(soft.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_soft + 4 * s * s_soft), int(nb[s]) * 4)
+            mine = po.CorrelateAccessCode(wl.access_code_string(), c4["threshold"]).work(po.binary_slicer_fb(soft))
+            assert np.array_equal(bits[s, :nb[s]], mine), (cpw, s)
+            softs.append(soft)
+            longest = max(longest, int(nb[s]))
+        ch.set_four_level(True, 0.01)
+        d_bits.zero_()
+        torch.cuda.synchronize()
+        ch.run_device(d_in, n, n, d_bits, 2 * n_out, d_n, st)
+        st.synchronize()
+        nb2 = d_n.cpu().numpy()
+        bits2 = d_bits.cpu().numpy()
+        for s in range(S):
+            assert nb2[s] == 2 * nb[s]
+            dib = po.unpack_k_bits_bb(2, po.PagerSlicer(0.01).work(softs[s]))
+            mine = po.CorrelateAccessCode(wl.access_code_string(), c4["threshold"]).work(dib)
+            assert np.array_equal(bits2[s, :nb2[s]], mine), (cpw, s)
+    # the strided walk was taken: more symbols than the grid covers (workgroups of 4 tiles of 8192 items)
+    assert longest > -(-int(n_out / omega * 1.125 + 4096) // 32768) * 32768, longest
+
+
 def test_chain_properties_full_size(gpu, wl):
     """one 10 M-sample capture (BASELINE size): sync flags appear every
     sync_period symbols, streams are independent and runs are reproducible."""

@@ -14,6 +14,11 @@ sys.path.insert(0, ROOT)
 import torch
 import grhip_loader
 
+CPW = None
+if "--cpw" in sys.argv:          # captures per wave of the clock recovery: 1 / 8 (default: the library's choice)
+    i = sys.argv.index("--cpw")
+    CPW = int(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 g = grhip_loader.import_grhip()
 wl = g.workload
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -34,6 +39,8 @@ d_n = torch.zeros(S, dtype=torch.int32, device=dev)
 ch = g.dmr_chain(decim, proto, c["center_freq"], c["fs"], c["demod_gain"], omega,
                  c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], wl.access_code_string(),
                  c4["threshold"], S, n)
+if CPW is not None:
+    ch.set_captures_per_wave(CPW)
 st = torch.cuda.Stream(device=dev)
 for _ in range(2):
     ch.run_device(d_in, n, n, d_bits, nout, d_n, st)
@@ -46,6 +53,8 @@ for _ in range(reps):
 e1.record(st)
 st.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(json.dumps({"workload": "full DMR chain (xlating+demod -> M&M -> slicer+correlator)", "streams": S, "decim": decim,
+print(json.dumps({"workload": "full DMR chain (xlating+demod -> M&M -> slicer+correlator)", "streams": S, "captures_per_wave": CPW, "decim": decim,
                   "ntaps": len(proto), "samples_per_stream": n, "ms_per_batch": ms, "Msamples_per_s": S * n / ms / 1e3,
                   "symbols": int(d_n[0].item())}))
+del ch        # (streams and events released before the interpreter tears the runtime down)
+torch.cuda.synchronize()
