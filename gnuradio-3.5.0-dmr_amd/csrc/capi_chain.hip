@@ -41,10 +41,10 @@ struct grhip_dmr_chain : HandleBase {
 #endif
     // clock recovery with eight captures per wave (mm_rows_kernel): 2048 captures are 256 waves, one per SIMD of 64 CUs,
     // and the FIR keeps two workgroups on each of the other CUs; from GRHIP_MM_ROWS_MIN captures on (below, one wave per
-    // capture has the shorter pass -- 0.145 against 0.2 us per symbol -- and there are SIMDs enough: 1536 captures run at
-    // 297-300 Gsamples/s that way and 261 this way, 2048 at 272 / 333-339, tools/gpu_chain_ab.sh)
+    // capture has the shorter pass -- 0.145 against 0.18 us per symbol -- and there are SIMDs enough; same box, one wave per
+    // capture / eight captures per wave: 1600 captures 313 / 317 Gsamples/s, 2048: 272 / 396; profiles/r02_chain_batch_sizes.log)
 #ifndef GRHIP_MM_ROWS_MIN
-#define GRHIP_MM_ROWS_MIN 1792
+#define GRHIP_MM_ROWS_MIN 1600
 #endif
 #ifndef GRHIP_CHAIN_WGCAP_ROWS
 #define GRHIP_CHAIN_WGCAP_ROWS 0
@@ -198,7 +198,8 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         const int NC = n_out >= 64 * 1024 ? grhip_dmr_chain::PIPE_CHUNKS : 1;
         const long long Lc = ((n_out + NC - 1) / NC + 63) / 64 * 64;       // slice length in outputs (rows stay 16-byte aligned)
         GRHIP_HIP(hipMemsetAsync(h->d_counts.p, 0, S * 2 * sizeof(int), st));
-        const int rows = h->mm_rows() ? 1 : 0;
+        // (ring of 1024 samples while four waves per CU of the loop's share hold the batch, else 512: see mm_rows_kernel)
+        const int rows = h->mm_rows() ? ((h->S + 7) / 8 <= 4 * GRHIP_MM_CUS ? 1024 : 512) : 0;
         // eight captures per wave: the loop and the FIR on CUs of their own (two masked streams)
         const bool split = rows && NC > 1 && h->st_mm8 && h->st_fir8;
         hipStream_t st_side = split ? h->st_mm8 : h->st2;
@@ -249,7 +250,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         // 2) M&M clock recovery, one wavefront per stream
         rc = launch_mm(h->d_mm.as<MMState>(), h->S, (int)n_out, (int)n_out, h->d_demod.as<float>(),
                        (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
-                       h->d_counts.as<int>(), h->tabs->mmse_rev, st, 0, h->mm_rows() ? 1 : 0);
+                       h->d_counts.as<int>(), h->tabs->mmse_rev, st, 0, h->mm_rows() ? 512 : 0);
         if (rc) return rc;
     }
 

@@ -17,7 +17,8 @@ struct MMState {
 // state[s], counts[2*s] = produced, counts[2*s+1] = consumed.
 // resume != 0: counts[] hold the stream's totals so far, the call continues from there with
 // noutput_items / ninput_items counted from the stream's start (see mm_kernel).
-// rows != 0: eight streams per wave (mm_rows_kernel; 16-byte aligned rows with 3 floats of slack behind ninput_items).
+// rows != 0: eight streams per wave (mm_rows_kernel; 16-byte aligned rows with 3 floats of slack behind ninput_items);
+// rows >= 1024: with the ring of 1024 samples (36 KB of LDS per wave), else 512 (20 KB).
 int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items, const float *in,
               long long in_stride, float *out, long long out_stride, int *counts,
               const float *mmse_rev, hipStream_t st, int resume = 0, int rows = 0);

@@ -166,11 +166,14 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
 // group of 8 lanes runs its own capture -- same instructions, same order of the float operations (bit-exact), eight
 // symbols per pass.  What was wave-uniform scalar state (sample position, counts) is group-uniform vector state; a
 // group that has to wait (window exhausted) or has finished is masked.
-//  * samples: a ring of 256 floats per capture in LDS (8 KB per wave + the 4 KB tap table: one such wave fits beside two
-//    FIR workgroups on a CU), topped up 128 at a time; the next 128 are requested into registers as soon as the previous
-//    chunk is accepted, so a top-up is an LDS write; a group accepts a chunk once it has left the older half of its
-//    ring, and every group that can accepts when any group must (the wave leaves the symbol loop at most once per
-//    128/omega symbols); a position outside the ring (a jump of the loop) re-seeds the ring there;
+//  * samples: a ring of MMR_RING floats per capture in LDS, topped up half a ring at a time; the next half is requested
+//    into registers as soon as the previous one is accepted, so a top-up is an LDS write -- and the request is half a ring
+//    ahead of its use: 512 samples = 51 symbols = 9 us at 10 samples per symbol with the ring of 1024 (36 KB of LDS per
+//    wave: four waves per CU), half that with the ring of 512 (20 KB: more waves per CU).  Beside a kernel that keeps HBM
+//    busy a request takes microseconds: 2048 captures beside the FIR run in 72 / 59 / 53 ms with rings of 256 / 512 /
+//    1024.  A group accepts a chunk once it has left the older half of its ring, and every group that can accepts when
+//    any group must (the wave leaves the symbol loop at most once per half ring); a position outside the ring (a jump
+//    of the loop) re-seeds the ring there;
 //  * the 8-tap sum is formed with the same DPP row shifts (the two groups of a 16-lane row do not meet in the lanes that
 //    count), the result goes to the group's lanes with a quad broadcast and a masked row shift;
 //  * outputs collect in one register per lane, a group stores 8 symbols (32 bytes) at a time.
@@ -178,13 +181,14 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
 // the caller guarantees 16-byte aligned rows with at least 3 floats of slack behind ninput_items (the chain's rows).
 // ---------------------------------------------------------------------------
 constexpr int MMR_RL = 8, MMR_ROWS = 64 / MMR_RL;
-constexpr int MMR_RING = 256, MMR_CHUNK = 128;
 
+template <int MMR_RING>
 __global__ void __launch_bounds__(64)
 mm_rows_kernel(MMState *__restrict__ state, int n_streams, int noutput_items, int ninput_items,
                const float *__restrict__ in, long long in_stride, float *__restrict__ out, long long out_stride,
                int *__restrict__ counts, const float *__restrict__ mmse_rev, int resume)
 {
+    constexpr int MMR_CHUNK = MMR_RING / 2;
     __shared__ __attribute__((aligned(16))) float s_ring[MMR_ROWS * MMR_RING];
     __shared__ float s_taps[MM_NTAPS * (MM_NSTEPS + 1)];
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -211,13 +215,14 @@ mm_rows_kernel(MMState *__restrict__ state, int n_streams, int noutput_items, in
     imu = imu < 0 ? 0 : (imu > MM_NSTEPS ? MM_NSTEPS : imu);
     bool fin = !valid || !(oo < noutput_items && ii < ni) || ii < 0;
     int lo = 0, hi = 0;                               // the ring holds samples [lo, hi)
-    f4 pf[4];
+    constexpr int NQ = MMR_CHUNK / (4 * MMR_RL);      // 16-byte loads per lane and chunk
+    f4 pf[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pf[q] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NQ; ++q) pf[q] = f4{0.f, 0.f, 0.f, 0.f};
 
     auto load_chunk = [&](int h) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int g = h + 32 * q + 4 * l;
             pf[q] = f4{0.f, 0.f, 0.f, 0.f};
             if (g < ninput_items) pf[q] = *reinterpret_cast<const f4 *>(x + g);
@@ -238,7 +243,7 @@ mm_rows_kernel(MMState *__restrict__ state, int n_streams, int noutput_items, in
             }
             if (ii >= hi - MMR_CHUNK) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < NQ; ++q)
                     *reinterpret_cast<f4 *>(&ring[(hi + 32 * q + 4 * l) & (MMR_RING - 1)]) = pf[q];
                 hi += MMR_CHUNK;
                 lo = lo > hi - MMR_RING ? lo : hi - MMR_RING;
@@ -329,8 +334,13 @@ int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items
     if (rows) {
         if ((((uintptr_t)in) & 15) || (in_stride & 3))
             return fail(GRHIP_EINVAL, "clock recovery, eight captures per wave: rows must be 16-byte aligned");
-        hipLaunchKernelGGL(mm_rows_kernel, dim3((n_streams + MMR_ROWS - 1) / MMR_ROWS), dim3(64), 0, st, state, n_streams,
-                           noutput_items, ninput_items, in, in_stride, out, out_stride, counts, mmse_rev, resume);
+        const dim3 grid((n_streams + MMR_ROWS - 1) / MMR_ROWS);
+        if (rows >= 1024)
+            hipLaunchKernelGGL(mm_rows_kernel<1024>, grid, dim3(64), 0, st, state, n_streams, noutput_items, ninput_items, in,
+                               in_stride, out, out_stride, counts, mmse_rev, resume);
+        else
+            hipLaunchKernelGGL(mm_rows_kernel<512>, grid, dim3(64), 0, st, state, n_streams, noutput_items, ninput_items, in,
+                               in_stride, out, out_stride, counts, mmse_rev, resume);
         GRHIP_HIP(hipGetLastError());
         return GRHIP_OK;
     }
