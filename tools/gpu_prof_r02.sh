@@ -7,7 +7,7 @@ O=$R/gpurun_out/prof_r02
 mkdir -p $O
 run() {    # name, script, args...
     name=$1; shift
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 "$@" > $O/$name.log 2>&1 || { echo "$name FAILED" >> $O/progress.log; return 1; }
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 "$@" > $O/$name.log 2>&1 || echo "$name: profiler exit code $?" >> $O/progress.log
     python3 - "$name" "$O" <<'PY'
 import csv, glob, sys
 s, o = sys.argv[1], sys.argv[2]
@@ -24,6 +24,8 @@ PY
 }
 run chain1024 $R/tools/bench_chain.py 1024
 run chain1536 $R/tools/bench_chain.py 1536
+run chain2048 $R/tools/bench_chain.py 2048
+run chain2432 $R/tools/bench_chain.py 2432
 run chain64 $R/tools/bench_chain.py 64
 run blocks $R/tools/bench_blocks.py
 run cfg3 $R/tools/bench_cfg3.py
