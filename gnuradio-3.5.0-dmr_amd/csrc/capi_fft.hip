@@ -168,14 +168,15 @@ int grhip_pfb_channelizer_ccf_create(grhip_pfb_channelizer_ccf **h, unsigned num
             hipError_t e = hipMemcpy(p->d_idxlut.p, p->idxlut.data(), numchans * sizeof(int), hipMemcpyHostToDevice);
             if (e != hipSuccess) rc = fail(GRHIP_ERUNTIME, "idxlut upload");
         }
-        std::vector<float2> dft(numchans);
+        std::vector<float2> dft(2 * (size_t)numchans);
         for (unsigned m = 0; m < numchans; ++m) {
             double ang = 2.0 * M_PI * (double)m / (double)numchans;     // FFTW_BACKWARD: +sign
             dft[m] = make_float2((float)cos(ang), (float)sin(ang));
+            dft[numchans + m] = make_float2((float)cos(-ang), (float)sin(-ang));    // forward table (batched-FFT kernels)
         }
-        if (!rc) rc = p->d_dft.reserve(numchans * sizeof(float2));
+        if (!rc) rc = p->d_dft.reserve(2 * (size_t)numchans * sizeof(float2));
         if (!rc) {
-            hipError_t e = hipMemcpy(p->d_dft.p, dft.data(), numchans * sizeof(float2), hipMemcpyHostToDevice);
+            hipError_t e = hipMemcpy(p->d_dft.p, dft.data(), 2 * (size_t)numchans * sizeof(float2), hipMemcpyHostToDevice);
             if (e != hipSuccess) rc = fail(GRHIP_ERUNTIME, "dft upload");
         }
     }

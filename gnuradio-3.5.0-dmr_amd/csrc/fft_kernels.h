@@ -19,7 +19,7 @@ struct PfbArgs {
     int rate_ratio;     // (int)rintf(M / oversample_rate)
     const float *ftaps; // [M][tpf] reversed taps (as gr_fir_ccf stores them)
     const int *idxlut;  // [M]
-    const float2 *dft;  // [M] exp(+2*pi*i*m/M)
+    const float2 *dft;  // [M] exp(+2*pi*i*m/M), followed by [M] exp(-2*pi*i*m/M) (the forward table launch_fft takes)
     const float2 *in;   // stream j at in + j*stride, item 0 = oldest history item
     long long stride;
     float2 *out;        // [nout][M]

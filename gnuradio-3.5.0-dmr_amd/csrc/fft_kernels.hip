@@ -807,6 +807,154 @@ static int launch_pfb_os1_any(const PfbArgs &a, hipStream_t st)
     return launch_pfb_os1_nt<M, 0>(a, lds, st);
 }
 
+// ---------------------------------------------------------------------------
+// Channel counts 32 / 64 / 128 at oversample_rate 1: the M polyphase FIRs in one kernel, the M-point backward DFTs in
+// the batched FFT kernel (fft16x_kernel, in place on the output).  A 256-lane workgroup takes a tile of TT = 8192 / M output
+// vectors; wave w runs streams w, w + 4, ... one after the other -- its own TT + tpf samples staged in a wave-private
+// LDS row (odd slot stride: conflict-free), R = TT / 64 consecutive outputs per lane with an R-deep register window, the
+// taps at a wave-uniform LDS address, the same fma order as pfb_os1_kernel -- and drops the filtered samples into the
+// tile's [t][slot] array in LDS; after one barrier the tile leaves as whole output vectors (M x 8 contiguous bytes per
+// t, 16-byte stores).  24 B of HBM traffic per sample more than the fused kernels (the vectors are written, read and
+// written again), against pfb_rows_kernel's strided accesses: M = 32 went from 38 to 150+ Gsamples/s.
+// ---------------------------------------------------------------------------
+template <int R, int M, int TP>       // TP: taps per filter padded to a compile-time count (0: any length, taps and window read in the loop)
+__global__ void __launch_bounds__(256)
+pfb_fir_t_kernel(const PfbArgs a)
+{
+    constexpr int TT = 64 * R;
+    constexpr int SPW = M / 4;                         // streams per wave
+    constexpr int NLM = R + 2;                         // 64-lane load rounds per stream: TT + tpfp + R <= 64 (R + 2) samples
+    typedef float pfb_f32x2 __attribute__((ext_vector_type(2)));
+    typedef float pfb_f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tpf = a.tpf;
+    const int tpfp = TP ? TP : (tpf + R - 1) / R * R;  // taps padded to a multiple of R (zeros)
+    constexpr int SW = M + 1;                          // slots per output vector in LDS (odd)
+    const int NS = TT + tpfp + R;                      // samples a stream stages per tile
+    const int XSW = NS + (R > 1 ? NS / R : 0) + 1;     // their slots: one pad slot per R samples (odd lane stride)
+    const int t = threadIdx.x, ln = t & 63, w = t >> 6;
+    pfb_f32x2 *sl = reinterpret_cast<pfb_f32x2 *>(smem);
+    pfb_f32x2 *xs = sl + (size_t)TT * SW + (size_t)w * XSW;
+    float *tl = reinterpret_cast<float *>(sl + (size_t)TT * SW + (size_t)4 * XSW) + (size_t)w * tpfp;
+    const long long items = a.nout + tpf;              // readable items of a stream (item 0 = oldest history item)
+
+    // persistent workgroups walk the tiles; all of the wave's samples of a tile are requested at once, and a stream's share
+    // of the NEXT tile as soon as its registers have been emptied into LDS: HBM latency runs under the FIRs and the stores
+    pfb_f32x2 pv[SPW][NLM];
+    auto request = [&](long long tile_, int js) __attribute__((always_inline)) {
+        const float2 *src = a.in + (long long)(w + 4 * js) * a.stride;
+#pragma unroll
+        for (int i = 0; i < NLM; ++i) {
+            const int m = ln + 64 * i;
+            const long long g = tile_ * TT + 1 + m;
+            pv[js][i] = pfb_f32x2{0.f, 0.f};
+            if (m < NS && g < items) { const float2 q = src[g]; pv[js][i] = pfb_f32x2{q.x, q.y}; }
+        }
+    };
+    const long long ntiles = (a.nout + TT - 1) / TT;
+    if ((long long)blockIdx.x < ntiles) {
+#pragma unroll
+        for (int js = 0; js < SPW; ++js) request(blockIdx.x, js);
+    }
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long t0 = tile * TT;
+    // (M = 128: a lane holds 192 registers of samples; with a second tile's loads live beside the FIR it runs out of them)
+    const bool more = M < 128 && tile + gridDim.x < ntiles;
+#pragma unroll
+    for (int js = 0; js < SPW; ++js) {
+        const int j = w + 4 * js;
+        const float *taps = a.ftaps + (size_t)(M - 1 - j) * tpf;
+#pragma unroll
+        for (int i = 0; i < NLM; ++i) {
+            const int m = ln + 64 * i;
+            if (m < NS) xs[m + (R > 1 ? m / R : 0)] = pv[js][i];
+        }
+        if (more) request(tile + gridDim.x, js);
+        for (int q = ln; q < tpfp; q += 64) tl[q] = q < tpf ? taps[q] : 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const pfb_f32x2 *xp = xs + ln * R + (R > 1 ? ln : 0);          // slot of sample R ln
+        pfb_f32x2 acc[R], win[R];
+        if (TP) {
+            // everything the lane needs in registers first (one LDS wait), then straight-line FMAs in the same order
+            pfb_f32x2 xv[R + (TP ? TP : 1) - 1];
+            float hq[TP ? TP : 1];
+#pragma unroll
+            for (int i = 0; i < R + TP - 1; ++i) xv[i] = xp[i + (R > 1 ? i / R : 0)];
+#pragma unroll
+            for (int q = 0; q < TP; ++q) hq[q] = tl[q];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = pfb_f32x2{0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < TP; ++q) {
+                const pfb_f32x2 hv = {hq[q], hq[q]};
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = __builtin_elementwise_fma(hv, xv[r + q], acc[r]);
+            }
+        } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { acc[r] = pfb_f32x2{0.f, 0.f}; win[r] = xp[r]; }
+        for (int q0 = 0; q0 < tpfp; q0 += R) {
+            const int nxt = q0 + R + (R > 1 ? q0 / R + 1 : 0);          // slot offset of sample R ln + q0 + R
+#pragma unroll
+            for (int qq = 0; qq < R; ++qq) {
+                const float h = tl[q0 + qq];
+                const pfb_f32x2 hv = {h, h};
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = __builtin_elementwise_fma(hv, win[(qq + r) % R], acc[r]);
+                win[qq] = xp[nxt + qq];
+            }
+        }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) sl[(size_t)(ln * R + r) * SW + (M - 1 - j)] = acc[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                               // the staging row belongs to the next stream
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    // the tile as whole output vectors: 16-byte piece p of vector tl holds slots 2p, 2p + 1
+    constexpr int PCS = M / 2;
+    for (int idx = t; idx < TT * PCS; idx += 256) {
+        const int row = idx / PCS, pc = idx - row * PCS;
+        if (t0 + row >= a.nout) break;
+        const pfb_f32x2 p0 = sl[(size_t)row * SW + 2 * pc], p1 = sl[(size_t)row * SW + 2 * pc + 1];
+        *reinterpret_cast<pfb_f32x4 *>(a.out + (t0 + row) * M + 2 * pc) = pfb_f32x4{p0.x, p0.y, p1.x, p1.y};
+    }
+    __syncthreads();                                   // sl belongs to the next tile from here
+    }
+}
+
+template <int R, int M, int TP>
+static int launch_pfb_fir_t_tp(const PfbArgs &a, hipStream_t st)
+{
+    constexpr int TT = 64 * R;
+    const int tpfp = TP ? TP : (a.tpf + R - 1) / R * R;
+    const int NS = TT + tpfp + R;
+    if (NS > 64 * (R + 2)) return -1;                  // (filters beyond ~120 taps per channel: the general kernel)
+    const int XSW = NS + (R > 1 ? NS / R : 0) + 1;
+    const size_t lds = ((size_t)TT * (M + 1) + (size_t)4 * XSW) * sizeof(float2) + (size_t)4 * tpfp * sizeof(float);
+    if (lds > 150 * 1024) return -1;
+    if (lds > 48 * 1024)
+        GRHIP_HIP(hipFuncSetAttribute((const void *)pfb_fir_t_kernel<R, M, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long ntiles = (a.nout + TT - 1) / TT;
+    const long long cap = M < 128 ? (long long)fft_num_cus() * (lds > 80 * 1024 ? 1 : 2) : ntiles;      // (M = 128: one tile per workgroup)
+    hipLaunchKernelGGL((pfb_fir_t_kernel<R, M, TP>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), lds, st, a);
+    GRHIP_HIP(hipGetLastError());
+    // the M-point backward DFT of every output vector, in place (unnormalised, as fftw's)
+    return launch_fft(M, 0, 0, nullptr, a.dft + M, a.out, a.out, a.nout, st);
+}
+
+template <int R, int M>
+static int launch_pfb_fir_t(const PfbArgs &a, hipStream_t st)
+{
+    // taps per filter up to 16 / 32: the FIR of a stream entirely in registers
+    if (a.tpf <= 16) return launch_pfb_fir_t_tp<R, M, 16>(a, st);
+    if (a.tpf <= 32) return launch_pfb_fir_t_tp<R, M, 32>(a, st);
+    return launch_pfb_fir_t_tp<R, M, 0>(a, st);
+}
+
 int launch_pfb(const PfbArgs &a, hipStream_t st)
 {
     if (a.nout <= 0) return GRHIP_OK;
@@ -831,6 +979,11 @@ int launch_pfb(const PfbArgs &a, hipStream_t st)
         case 14: rc = launch_pfb_os1_any<14>(a, st); break;
         case 15: rc = launch_pfb_os1_any<15>(a, st); break;
         }
+        if (rc != -1) return rc;
+        // 32 / 64 / 128 channels: polyphase FIRs + batched FFT
+        if (a.M == 32) rc = launch_pfb_fir_t<4, 32>(a, st);
+        else if (a.M == 64) rc = launch_pfb_fir_t<2, 64>(a, st);
+        else if (a.M == 128) rc = launch_pfb_fir_t<1, 128>(a, st);
         if (rc != -1) return rc;
     }
     if (a.M <= 64) {

@@ -100,7 +100,8 @@ def _pfb_streams(x, M, tpf):
 
 
 @pytest.mark.parametrize("M,ntaps", [(8, 256), (8, 250), (4, 33), (16, 64), (3, 10), (1, 5), (5, 100), (6, 50), (7, 7), (9, 300),
-                                     (10, 200), (11, 33), (12, 96), (13, 130), (14, 28), (15, 64), (20, 100), (32, 64)])
+                                     (10, 200), (11, 33), (12, 96), (13, 130), (14, 28), (15, 64), (20, 100), (32, 64),
+                                     (32, 1000), (64, 640), (64, 70), (128, 1024), (128, 2500), (256, 512)])
 def test_pfb_vs_oracle(gpu, po, M, ntaps):
     rng = np.random.default_rng(M * 1000 + ntaps)
     nout = 1500
@@ -120,7 +121,9 @@ def test_pfb_vs_oracle(gpu, po, M, ntaps):
 
 
 @pytest.mark.parametrize("M,tpf,nout", [(8, 32, 512 * 2400 + 77), (8, 8, 512 * 1600 + 1), (8, 48, 512 * 800 + 63),
-                                        (4, 32, 512 * 3200 + 5), (10, 20, 512 * 1500 + 9), (5, 33, 512 * 2000 + 311)])
+                                        (4, 32, 512 * 3200 + 5), (10, 20, 512 * 1500 + 9), (5, 33, 512 * 2000 + 311),
+                                        (32, 16, 256 * 1500 + 77), (64, 10, 128 * 1100 + 1), (128, 33, 64 * 900 + 63),
+                                        (32, 30, 256 * 700 + 5), (64, 40, 128 * 500 + 17), (128, 16, 64 * 1000)])
 def test_pfb_persistent_walk(gpu, po, M, tpf, nout):
     """more tiles than resident workgroups: every workgroup walks several tiles (the next tile's samples in flight), and a
     ragged last tile whose vectors past nout fall outside the store descriptor; tpf 32 / 8: taps resident in SGPRs,

@@ -10,7 +10,7 @@ wl = g.workload
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev)
 tot = 1 << 26
-for M, tpf in ((2, 32), (4, 32), (8, 32), (16, 32), (8, 64), (8, 16), (32, 16), (5, 20), (10, 20), (12, 32), (15, 16)):
+for M, tpf in ((2, 32), (4, 32), (8, 32), (16, 32), (8, 64), (8, 16), (32, 16), (32, 32), (64, 16), (128, 16), (5, 20), (10, 20), (12, 32), (15, 16)):
     nout = (tot // M) // 512 * 512
     taps = wl.lowpass_taps(M * tpf, 0.5 / M, 1.0)
     pf = g.pfb_channelizer_ccf(M, taps, 1.0)
@@ -24,5 +24,5 @@ for M, tpf in ((2, 32), (4, 32), (8, 32), (16, 32), (8, 64), (8, 16), (32, 16), 
     for _ in range(10): pf.general_work_device(nout, xs, per, yo, st)
     e1.record(st); st.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    print("M=%2d taps/filter %3d  %7.1f Gsamples/s  frac %.3f" % (M, tpf, tot / ms / 1e6, tot * 16 / (ms * 1e-3) / 8e12), flush=True)
+    print("M=%3d taps/filter %3d  %7.1f Gsamples/s  frac %.3f" % (M, tpf, tot / ms / 1e6, tot * 16 / (ms * 1e-3) / 8e12), flush=True)
     del xs, yo
