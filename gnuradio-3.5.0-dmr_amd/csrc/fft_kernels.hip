@@ -822,6 +822,7 @@ __global__ void __launch_bounds__(256)
 pfb_fir_t_kernel(const PfbArgs a)
 {
     constexpr int TT = 64 * R;
+    constexpr bool FUSE = M == 32 || M == 64;          // the DFT in this kernel too (one / two lanes per output vector)
     constexpr int SPW = M / 4;                         // streams per wave
     constexpr int NLM = R + 2;                         // 64-lane load rounds per stream: TT + tpfp + R <= 64 (R + 2) samples
     typedef float pfb_f32x2 __attribute__((ext_vector_type(2)));
@@ -858,8 +859,9 @@ pfb_fir_t_kernel(const PfbArgs a)
     }
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long t0 = tile * TT;
-    // (M = 128: a lane holds 192 registers of samples; with a second tile's loads live beside the FIR it runs out of them)
-    const bool more = M < 128 && tile + gridDim.x < ntiles;
+    // (M = 64 / 128: a lane holds 128 / 192 registers of samples; with a second tile's loads live beside the FIR and the DFT it
+    // runs out of them: one tile per workgroup)
+    const bool more = M < 64 && tile + gridDim.x < ntiles;
 #pragma unroll
     for (int js = 0; js < SPW; ++js) {
         const int j = w + 4 * js;
@@ -914,6 +916,61 @@ pfb_fir_t_kernel(const PfbArgs a)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     __syncthreads();
+    if (FUSE) {
+        // the backward DFT of the tile's output vectors in registers (no second kernel, no intermediate in HBM).  M = 32:
+        // one vector per lane; M = 64: two lanes per vector -- each the 32-point DFT of the even / odd slots (bit-reversed
+        // load, radix-2 decimation-in-time stages as in pfb_os1_kernel), then the last radix-2 stage across the lane pair:
+        // the odd lane turns its half by e^{+2 pi i k / 64}, the two swap through a quad permute, the even lane keeps
+        // E + T = outputs 0..31, the odd one E - T = outputs 32..63 -- and back into the vector's own LDS row.
+        const pfb_cfloat_p dft = (pfb_cfloat_p)(a.dft);
+        constexpr int LPV = M / 32, LOGP = 5, P = 32;
+        static_assert(!FUSE || TT * LPV == 256, "every lane has its share of a vector");
+        const int half = t & (LPV - 1);
+        pfb_f32x2 *row = sl + (size_t)(t / LPV) * SW;
+        float2 v[P];
+#pragma unroll
+        for (int s_ = 0; s_ < P; ++s_) {
+            int rv = 0;
+#pragma unroll
+            for (int bit = 0; bit < LOGP; ++bit)
+                if (s_ & (1 << bit)) rv |= (P >> 1) >> bit;
+            const pfb_f32x2 u = row[LPV * s_ + half];
+            v[rv] = make_float2(u.x, u.y);
+        }
+#pragma unroll
+        for (int stg = 0; stg < LOGP; ++stg) {
+            const int len = 2 << stg;
+            const int hl = len >> 1, step = M / len;
+#pragma unroll
+            for (int s0 = 0; s0 < P; s0 += len) {
+#pragma unroll
+                for (int k = 0; k < hl; ++k) {
+                    const float wr = dft[2 * (k * step)], wi = dft[2 * (k * step) + 1];   // e^{+2 pi i k/len}
+                    const float2 u = v[s0 + k], q = v[s0 + k + hl];
+                    const float2 tw = (k == 0) ? q : make_float2(__builtin_fmaf(q.x, wr, -(q.y * wi)),
+                                                                 __builtin_fmaf(q.x, wi, q.y * wr));
+                    v[s0 + k] = make_float2(u.x + tw.x, u.y + tw.y);
+                    v[s0 + k + hl] = make_float2(u.x - tw.x, u.y - tw.y);
+                }
+            }
+        }
+        if (LPV == 2) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float wr = dft[2 * k], wi = dft[2 * k + 1];
+                const float2 q = v[k];
+                // the odd lane's half turned (k = 0: as it is)
+                const float2 mine = (half && k) ? make_float2(__builtin_fmaf(q.x, wr, -(q.y * wi)), __builtin_fmaf(q.x, wi, q.y * wr)) : q;
+                const float ox = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine.x), 0xB1, 0xf, 0xf, true));
+                const float oy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine.y), 0xB1, 0xf, 0xf, true));
+                v[k] = half ? make_float2(ox - mine.x, oy - mine.y) : make_float2(mine.x + ox, mine.y + oy);
+            }
+        }
+        // (a vector's row belongs to its lane(s), which sit side by side in one wave: no barrier between their reads and writes)
+#pragma unroll
+        for (int k = 0; k < P; ++k) row[P * half + k] = pfb_f32x2{v[k].x, v[k].y};
+        __syncthreads();
+    }
     // the tile as whole output vectors: 16-byte piece p of vector tl holds slots 2p, 2p + 1
     constexpr int PCS = M / 2;
     for (int idx = t; idx < TT * PCS; idx += 256) {
@@ -939,9 +996,10 @@ static int launch_pfb_fir_t_tp(const PfbArgs &a, hipStream_t st)
     if (lds > 48 * 1024)
         GRHIP_HIP(hipFuncSetAttribute((const void *)pfb_fir_t_kernel<R, M, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long ntiles = (a.nout + TT - 1) / TT;
-    const long long cap = M < 128 ? (long long)fft_num_cus() * (lds > 80 * 1024 ? 1 : 2) : ntiles;      // (M = 128: one tile per workgroup)
+    const long long cap = M < 64 ? (long long)fft_num_cus() * (lds > 80 * 1024 ? 1 : 2) : ntiles;      // (M = 64 / 128: one tile per workgroup)
     hipLaunchKernelGGL((pfb_fir_t_kernel<R, M, TP>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), lds, st, a);
     GRHIP_HIP(hipGetLastError());
+    if (M == 32 || M == 64) return GRHIP_OK;           // (the kernel has done the DFT)
     // the M-point backward DFT of every output vector, in place (unnormalised, as fftw's)
     return launch_fft(M, 0, 0, nullptr, a.dft + M, a.out, a.out, a.nout, st);
 }
