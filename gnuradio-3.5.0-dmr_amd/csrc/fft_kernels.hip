@@ -822,7 +822,7 @@ __global__ void __launch_bounds__(256)
 pfb_fir_t_kernel(const PfbArgs a)
 {
     constexpr int TT = 64 * R;
-    constexpr bool FUSE = M == 32 || M == 64;          // the DFT in this kernel too (one / two lanes per output vector)
+    constexpr bool FUSE = M <= 64;                     // the DFT in this kernel too (one / two lanes per output vector)
     constexpr int SPW = M / 4;                         // streams per wave
     constexpr int NLM = R + 2;                         // 64-lane load rounds per stream: TT + tpfp + R <= 64 (R + 2) samples
     typedef float pfb_f32x2 __attribute__((ext_vector_type(2)));
@@ -954,21 +954,38 @@ pfb_fir_t_kernel(const PfbArgs a)
                 }
             }
         }
-        if (LPV == 2) {
+        // radix-2 stages across the lanes of a vector: lane `half` holds the P-point DFT of the slots = half (mod LPV).
+        // Stage with partner lane ^ XR combines two DFTs of L points into one of 2 L: the upper lane of the pair (bit XR of
+        // `half` set) turns its values by e^{+2 pi i (k + off) / (2 L)}, the two swap through a quad permute, the lower lane
+        // keeps A + T (outputs off + k), the upper one A - T (outputs off + k + L), off = the block of L outputs the lanes hold.
+        auto cross = [&](const bool upper, const int tw_index_base, const int tw_step, const bool swap2) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                const float wr = dft[2 * k], wi = dft[2 * k + 1];
+                const int ti = tw_index_base + tw_step * k;            // index into the M-entry table e^{+2 pi i m / M}
+                const float wr = dft[2 * ti], wi = dft[2 * ti + 1];
                 const float2 q = v[k];
-                // the odd lane's half turned (k = 0: as it is)
-                const float2 mine = (half && k) ? make_float2(__builtin_fmaf(q.x, wr, -(q.y * wi)), __builtin_fmaf(q.x, wi, q.y * wr)) : q;
-                const float ox = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine.x), 0xB1, 0xf, 0xf, true));
-                const float oy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine.y), 0xB1, 0xf, 0xf, true));
-                v[k] = half ? make_float2(ox - mine.x, oy - mine.y) : make_float2(mine.x + ox, mine.y + oy);
+                const float2 mine = upper ? make_float2(__builtin_fmaf(q.x, wr, -(q.y * wi)), __builtin_fmaf(q.x, wi, q.y * wr)) : q;
+                float ox, oy;
+                if (swap2) {
+                    ox = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine.x), 0x4E, 0xf, 0xf, true));
+                    oy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine.y), 0x4E, 0xf, 0xf, true));
+                } else {
+                    ox = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine.x), 0xB1, 0xf, 0xf, true));
+                    oy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mine.y), 0xB1, 0xf, 0xf, true));
+                }
+                v[k] = upper ? make_float2(ox - mine.x, oy - mine.y) : make_float2(mine.x + ox, mine.y + oy);
             }
+        };
+        int oslot = 0;                                                 // first output slot of the lane's 32
+        if (LPV == 2) {
+            cross(half != 0, 0, 1, false);                             // 32 + 32 -> 64: twiddle e^{+2 pi i k / 64}
+            oslot = P * half;
         }
+        // (four lanes per vector at M = 128 -- two such stages, partners lane ^ 2 then lane ^ 1 -- were built and passed the
+        // tests, but with 192 registers of samples per lane the kernel ran at 91 Gsamples/s against 110 for the two-kernel form)
         // (a vector's row belongs to its lane(s), which sit side by side in one wave: no barrier between their reads and writes)
 #pragma unroll
-        for (int k = 0; k < P; ++k) row[P * half + k] = pfb_f32x2{v[k].x, v[k].y};
+        for (int k = 0; k < P; ++k) row[oslot + k] = pfb_f32x2{v[k].x, v[k].y};
         __syncthreads();
     }
     // the tile as whole output vectors: 16-byte piece p of vector tl holds slots 2p, 2p + 1
@@ -999,7 +1016,7 @@ static int launch_pfb_fir_t_tp(const PfbArgs &a, hipStream_t st)
     const long long cap = M < 64 ? (long long)fft_num_cus() * (lds > 80 * 1024 ? 1 : 2) : ntiles;      // (M = 64 / 128: one tile per workgroup)
     hipLaunchKernelGGL((pfb_fir_t_kernel<R, M, TP>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), lds, st, a);
     GRHIP_HIP(hipGetLastError());
-    if (M == 32 || M == 64) return GRHIP_OK;           // (the kernel has done the DFT)
+    if (M <= 64) return GRHIP_OK;                      // (the kernel has done the DFT)
     // the M-point backward DFT of every output vector, in place (unnormalised, as fftw's)
     return launch_fft(M, 0, 0, nullptr, a.dft + M, a.out, a.out, a.nout, st);
 }
