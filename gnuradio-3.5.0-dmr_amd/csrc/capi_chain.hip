@@ -199,16 +199,20 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         const long long Lc = ((n_out + NC - 1) / NC + 63) / 64 * 64;       // slice length in outputs (rows stay 16-byte aligned)
         GRHIP_HIP(hipMemsetAsync(h->d_counts.p, 0, S * 2 * sizeof(int), st));
         // (ring of 1024 samples while four waves per CU of the loop's share hold the batch, else 512: see mm_rows_kernel)
-        const int rows = h->mm_rows() ? ((h->S + 7) / 8 <= 4 * GRHIP_MM_CUS ? 1024 : 512) : 0;
+        // (without the masked streams -- their creation failed -- the loop and the FIR share every CU: the batch-size rule then
+        // keeps one wave per capture; a forced 8 runs with the small ring beside a FIR held to one workgroup per CU)
+        const bool masks = h->st_mm8 && h->st_fir8;
+        const bool want_rows = h->mm_rows() && (masks || h->captures_per_wave == 8);
+        const int rows = want_rows ? (masks && (h->S + 7) / 8 <= 4 * GRHIP_MM_CUS ? 1024 : 512) : 0;
         // eight captures per wave: the loop and the FIR on CUs of their own (two masked streams)
-        const bool split = rows && NC > 1 && h->st_mm8 && h->st_fir8;
+        const bool split = rows && NC > 1 && masks;
         hipStream_t st_side = split ? h->st_mm8 : h->st2;
         hipStream_t st_fir = split ? h->st_fir8 : st;
         GRHIP_HIP(hipEventRecord(h->ev_begin, st));
         GRHIP_HIP(hipStreamWaitEvent(st_side, h->ev_begin, 0));
         if (split) GRHIP_HIP(hipStreamWaitEvent(st_fir, h->ev_begin, 0));
         st_mm = NC > 1 ? st_side : st;
-        h->core.mf_wg_cap = NC > 1 ? (rows ? GRHIP_CHAIN_WGCAP_ROWS : GRHIP_CHAIN_WGCAP) : 0;
+        h->core.mf_wg_cap = NC > 1 ? (split ? GRHIP_CHAIN_WGCAP_ROWS : GRHIP_CHAIN_WGCAP) : 0;
         h->core.mf_cu_cap = split ? h->fir8_cus : 0;
         for (int c = 0; c < NC; ++c) {
             const long long o0 = (long long)c * Lc;
