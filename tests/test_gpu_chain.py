@@ -234,6 +234,59 @@ def test_chain_eight_captures_per_wave(gpu, po, wl, decim, ntaps, n_out, omega):
     assert np.array_equal(outs[8][0], outs[1][0]) and np.array_equal(outs[8][1], outs[1][1])
 
 
+@pytest.mark.parametrize("S", [1600, 2100])
+def test_chain_big_batches_take_the_eight_captures_form_by_themselves(gpu, po, wl, S):
+    """batches of 1600 captures and more: the library's own choice of the clock-recovery form (eight captures per wave, the
+    loop and the FIR on CUs of their own; 2100 captures: the smaller ring), time-sliced.  Few distinct captures repeated over
+    the batch: every copy must give what its original gives, the originals are checked stage by stage, and forcing one wave
+    per capture reproduces the batch bit for bit."""
+    import ctypes
+    torch = _torch()
+    c, c4 = wl.CFG2, wl.CFG4
+    n_out = 70_000
+    n = n_out * 4
+    K = 5                                               # distinct captures
+    xs = [wl.fsk4_capture(n, stream_id=80 + k) for k in range(K)]
+    dev = torch.device("cuda", 0)
+    d_in = torch.empty((S, n, 2), dtype=torch.float32, device=dev)
+    src = [torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev) for x in xs]
+    for s in range(S):
+        d_in[s] = src[s % K]
+    d_bits = torch.zeros((S, n_out), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    ch = _make_chain(gpu, wl, S, n)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    ch.run_device(d_in, n, n, d_bits, n_out, d_n, st)
+    st.synchronize()
+    nb = d_n.cpu().numpy()
+    bits = d_bits.cpu().numpy()
+    p_dem, s_dem = ch.intermediate(0)
+    p_soft, s_soft = ch.intermediate(1)
+    for k in range(K):
+        dem = np.empty(n_out, np.float32)
+        gpu.lib().grhip_memcpy_d2h(dem.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_dem + 4 * k * s_dem), n_out * 4)
+        dem_ref, _, _ = _oracle_chain(po, wl, xs[k])
+        ok, worst = demod_close(dem, dem_ref)
+        assert ok, (k, worst)
+        ref, _ = po.chain_mm(c4["omega"], c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], dem)
+        assert nb[k] == len(ref)
+        soft = np.empty(nb[k], np.float32)
+        gpu.lib().grhip_memcpy_d2h(soft.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_soft + 4 * k * s_soft), int(nb[k]) * 4)
+        assert bits_equal(soft, ref), k
+        mine = po.CorrelateAccessCode(wl.access_code_string(), c4["threshold"]).work(po.binary_slicer_fb(soft))
+        assert np.array_equal(bits[k, :nb[k]], mine)
+    for s in range(K, S):                               # every copy like its original
+        assert nb[s] == nb[s % K] and np.array_equal(bits[s, :nb[s]], bits[s % K, :nb[s]]), s
+    first = bits.copy()
+    ch.set_captures_per_wave(1)
+    d_bits.zero_()
+    torch.cuda.synchronize()
+    ch.run_device(d_in, n, n, d_bits, n_out, d_n, st)
+    st.synchronize()
+    assert np.array_equal(d_n.cpu().numpy(), nb) and np.array_equal(d_bits.cpu().numpy(), first)
+
+
 def test_chain_more_symbols_than_the_nominal_clock_gives(gpu, po, wl):
     """the stages behind the clock recovery size their grids by the nominal symbol count (+ 12.5 %) and walk longer streams
     in strides: a 2-samples-per-symbol loop allowed to go down to 1.1 (the limit is absolute: digital_clock_recovery_mm_ff.cc:124),
