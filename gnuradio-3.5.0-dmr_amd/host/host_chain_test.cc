@@ -5,6 +5,7 @@
 // that drives it and writes each stage's output for comparison with the oracle.
 //
 // usage: host_chain_test <dir> <mode: chain|errors>
+#include <cstring>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -61,7 +62,18 @@ static int test_errors()
 // what grhip_fir_sysconfig adds.
 // the reference's generators: srandom(0), rint(uniform() * 32767) (qa_gr_fir_ccf.cc:63-85; 32768 for fff,
 // qa_gr_fir_fff.cc:120-131) -- glibc's random() gives the very sequence the reference's own run uses
-static float qa_uniform() { return 2.0 * ((float)random() / 2147483647.0 - 0.5); }
+// (through random_r on a state of our own -- 128 bytes: the generator random() itself uses -- because random()'s state is
+// process-wide and the GPU runtime's threads draw from it now and then: a run whose sequence had been shifted got other data,
+// among them an output whose terms cancel to 2e-4 of their size, which no float32 sum reproduces to 1e-5 of the result)
+static struct random_data qa_rd;
+static char qa_rd_state[128];
+static void qa_srandom(unsigned seed)
+{
+    memset(&qa_rd, 0, sizeof(qa_rd));
+    initstate_r(seed, qa_rd_state, sizeof(qa_rd_state), &qa_rd);
+}
+static long qa_random() { int32_t r = 0; random_r(&qa_rd, &r); return r; }
+static float qa_uniform() { return 2.0 * ((float)qa_random() / 2147483647.0 - 0.5); }
 template <class T> static T rnd_item(float scale);
 template <> float rnd_item<float>(float scale) { return (float)rint(qa_uniform() * scale); }
 template <> gr_complex rnd_item<gr_complex>(float scale)
@@ -76,7 +88,7 @@ static int qa_one_signature(const char *sig, void (*get_info)(std::vector<INFO> 
     get_info(&info);
     int fails = 0, cases = 0;
     for (auto &p : info) {
-        srandom(0);          // we want reproducibility (qa_gr_fir_ccf.cc:118)
+        qa_srandom(0);       // we want reproducibility (qa_gr_fir_ccf.cc:118)
         const int OUTPUT_LEN = 17, INPUT_LEN = MAX_TAPS + OUTPUT_LEN;
         for (int n = 0; n <= MAX_TAPS; n++)
             for (int ol = 0; ol <= OUTPUT_LEN; ol++) {
@@ -92,14 +104,21 @@ static int qa_one_signature(const char *sig, void (*get_info)(std::vector<INFO> 
                     std::complex<double> sum = 0;
                     for (int i = 0; i < n; i++) sum += std::complex<double>(input[o + i]) * std::complex<double>(taps[n - i - 1]);
                     const std::complex<double> got(actual[o]);
-                    if (std::abs(got - sum) > std::abs(sum) * tol) fails++;
+                    if (std::abs(got - sum) > std::abs(sum) * tol) {
+                        fails++;
+                        std::cout << "  filterN: " << sig << " ntaps " << n << " outputs " << ol << " output " << o << ": got " << got
+                                  << " expected " << sum << "\n";
+                    }
                     cases++;
                 }
                 if (n > 0 && ol > 0) {       // filter() = one output (it may take another engine: same tolerance); get_taps()
                     const std::complex<double> one(f1->filter(input.data()));
                     std::complex<double> sum0 = 0;
                     for (int i = 0; i < n; i++) sum0 += std::complex<double>(input[i]) * std::complex<double>(taps[n - i - 1]);
-                    if (std::abs(one - sum0) > std::abs(sum0) * tol) fails++;
+                    if (std::abs(one - sum0) > std::abs(sum0) * tol) {
+                        fails++;
+                        std::cout << "  filter: " << sig << " ntaps " << n << " (after filterN of " << ol << "): got " << one << " expected " << sum0 << "\n";
+                    }
                     if (f1->get_taps() != f1_taps || f1->ntaps() != (unsigned)n) fails++;
                 }
                 delete f1;
@@ -119,7 +138,10 @@ static int qa_one_signature(const char *sig, void (*get_info)(std::vector<INFO> 
             for (int o = 0; o < N; o++) {
                 std::complex<double> sum = 0;
                 for (int i = 0; i < T; i++) sum += std::complex<double>(input[o * D + i]) * std::complex<double>(t2[T - i - 1]);
-                if (std::abs(std::complex<double>(out[o]) - sum) > std::abs(sum) * tol) fails++;
+                if (std::abs(std::complex<double>(out[o]) - sum) > std::abs(sum) * tol) {
+                    fails++;
+                    std::cout << "  filterNdec: " << sig << " output " << o << ": got " << std::complex<double>(out[o]) << " expected " << sum << "\n";
+                }
                 cases++;
             }
             delete f;
