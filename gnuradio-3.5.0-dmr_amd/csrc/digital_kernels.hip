@@ -365,7 +365,7 @@ pager_slicer_kernel(float *__restrict__ d_avg, float alpha, float beta, const fl
                     long long in_stride, unsigned char *__restrict__ out, long long out_stride, long long n,
                     const int *__restrict__ n_ptr, int n_ptr_stride)
 {
-    __shared__ float s_x[PS_CH], s_t[PS_CH];
+    __shared__ __attribute__((aligned(16))) float s_x[PS_CH], s_t[PS_CH];
     const int s = blockIdx.x, lane = threadIdx.x;
     if (n_ptr) {
         const long long m = n_ptr[(long long)s * n_ptr_stride];
@@ -392,12 +392,39 @@ pager_slicer_kernel(float *__restrict__ d_avg, float alpha, float beta, const fl
             }
         }
         __syncthreads();
-        for (int i = 0; i < m; ++i) {
-            avg = avg * beta + s_t[i];              // .cc:52
+        // whole groups of 64 samples: sixteen of the alpha x at a time into registers (one LDS wait per sixteen), the recurrence
+        // in registers -- the same two unfused operations per sample, in every lane -- and lane l keeps the average of the
+        // group's sample l for its decision (round 2 until then: an LDS read, the two operations and an LDS store per sample
+        // in one dependent chain: 16.6 ms for 2048 captures of 250 k symbols; this form 12.4 ms; storing the averages to LDS
+        // from one lane, sixteen at a time, measured no better than the original)
+        typedef float ps_f4 __attribute__((ext_vector_type(4)));
+        const int mg = m & ~63;
+        for (int g0 = 0; g0 < mg; g0 += 64) {
+            float kp = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const ps_f4 *tp = reinterpret_cast<const ps_f4 *>(&s_t[g0 + 16 * c]);
+                const ps_f4 ta = tp[0], tb = tp[1], tc = tp[2], td = tp[3];
+                const float tv[16] = {ta[0], ta[1], ta[2], ta[3], tb[0], tb[1], tb[2], tb[3], tc[0], tc[1], tc[2], tc[3], td[0], td[1], td[2], td[3]};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    avg = avg * beta + tv[j];       // .cc:52
+                    kp = lane == 16 * c + j ? avg : kp;
+                }
+            }
+            const int i = g0 + lane;
+            const float sample = s_x[i] - kp;       // .cc:53
+            unsigned char d;
+            if (sample > 0) d = (sample > 2.0f) ? 3 : 2;
+            else d = (sample < -2.0f) ? 0 : 1;
+            y[base + i] = d;
+        }
+        for (int i = mg; i < m; ++i) {              // the stream's last, partial group
+            avg = avg * beta + s_t[i];
             s_t[i] = avg;
         }
         __syncthreads();
-        for (int i = lane; i < m; i += 64) {
+        for (int i = mg + lane; i < m; i += 64) {
             const float sample = s_x[i] - s_t[i];   // .cc:53
             unsigned char d;
             if (sample > 0) d = (sample > 2.0f) ? 3 : 2;
@@ -453,6 +480,27 @@ unpack_k_bits_streams_kernel(unsigned k, const unsigned char *__restrict__ in, l
     const unsigned char *__restrict__ x = in + (long long)s * in_stride;
     unsigned char *__restrict__ y = out + (long long)s * out_stride;
     if (n_out && blockIdx.x == 0 && threadIdx.x == 0) n_out[(long long)s * n_out_stride] = (int)n;
+    if (k == 2 && (((uintptr_t)x) & 7) == 0 && (((uintptr_t)y) & 15) == 0) {
+        // dibits: 8 symbols (one 8-byte load) -> 16 bits (one 16-byte store) per lane and trip (it was a byte store per bit)
+        const long long n8 = n_in >> 3;
+        for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (long long)gridDim.x * blockDim.x) {
+            const uint2 v = reinterpret_cast<const uint2 *>(x)[c];
+            // byte b of a word -> bytes (2b, 2b+1) = (bit 1, bit 0) of the symbol
+            auto spread = [](unsigned w2) -> unsigned {      // two symbols (low 16 bits: s0 | s1 << 8) -> four output bytes
+                const unsigned s0 = w2 & 0xffu, s1 = (w2 >> 8) & 0xffu;
+                return ((s0 >> 1) & 1u) | ((s0 & 1u) << 8) | (((s1 >> 1) & 1u) << 16) | ((s1 & 1u) << 24);
+            };
+            uint4 o;
+            o.x = spread(v.x); o.y = spread(v.x >> 16); o.z = spread(v.y); o.w = spread(v.y >> 16);
+            reinterpret_cast<uint4 *>(y)[c] = o;
+        }
+        for (long long i = 16 * n8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const long long q = i / k;
+            const unsigned j = k - 1 - (unsigned)(i - q * k);
+            y[i] = (unsigned char)(((unsigned)x[q] >> j) & 1u);
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long q = i / k;
         const unsigned j = k - 1 - (unsigned)(i - q * k);

@@ -15,6 +15,9 @@ import torch
 import grhip_loader
 
 CPW = None
+FOUR = "--four" in sys.argv          # the 4FSK tail (pager slicer -> dibits -> correlator) instead of the binary slicer
+if FOUR:
+    sys.argv.remove("--four")
 if "--cpw" in sys.argv:          # captures per wave of the clock recovery: 1 / 8 (default: the library's choice)
     i = sys.argv.index("--cpw")
     CPW = int(sys.argv[i + 1])
@@ -41,19 +44,22 @@ ch = g.dmr_chain(decim, proto, c["center_freq"], c["fs"], c["demod_gain"], omega
                  c4["threshold"], S, n)
 if CPW is not None:
     ch.set_captures_per_wave(CPW)
+if FOUR:
+    ch.set_four_level(True, 0.001)
+    d_bits = torch.zeros((S, 2 * nout), dtype=torch.uint8, device=dev)
 st = torch.cuda.Stream(device=dev)
 for _ in range(2):
-    ch.run_device(d_in, n, n, d_bits, nout, d_n, st)
+    ch.run_device(d_in, n, n, d_bits, (2 if FOUR else 1) * nout, d_n, st)
 st.synchronize()
 reps = 5
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(st)
 for _ in range(reps):
-    ch.run_device(d_in, n, n, d_bits, nout, d_n, st)
+    ch.run_device(d_in, n, n, d_bits, (2 if FOUR else 1) * nout, d_n, st)
 e1.record(st)
 st.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(json.dumps({"workload": "full DMR chain (xlating+demod -> M&M -> slicer+correlator)", "streams": S, "captures_per_wave": CPW, "decim": decim,
+print(json.dumps({"workload": "full DMR chain (xlating+demod -> M&M -> slicer+correlator)", "streams": S, "four_level": FOUR, "captures_per_wave": CPW, "decim": decim,
                   "ntaps": len(proto), "samples_per_stream": n, "ms_per_batch": ms, "Msamples_per_s": S * n / ms / 1e3,
                   "symbols": int(d_n[0].item())}))
 del ch        # (streams and events released before the interpreter tears the runtime down)
