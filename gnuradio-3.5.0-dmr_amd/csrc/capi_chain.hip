@@ -237,6 +237,13 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
             if (rc) { h->core.mf_wg_cap = 0; h->core.mf_cu_cap = 0; return rc; }
         }
         h->core.mf_cu_cap = 0;
+        if (split) {
+            // what follows the loop (slicers, unpack, correlator) has the whole device again: on the loop's masked stream
+            // 2048 single-wave workgroups shared 64 CUs (pager slicer 12.4 ms instead of 2.x, correlator 2.0 instead of 0.4)
+            GRHIP_HIP(hipEventRecord(h->ev_end, st_side));
+            GRHIP_HIP(hipStreamWaitEvent(st, h->ev_end, 0));
+            st_mm = st;
+        }
         h->core.mf_wg_cap = 0;
     } else {
         // generic order: explicit zero history in a scratch row, one stream at a time
