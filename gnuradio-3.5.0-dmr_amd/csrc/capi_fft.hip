@@ -9,7 +9,8 @@ using namespace grhip;
 struct grhip_fft_vcc : HandleBase {
     int N = 0, forward = 1, shift = 0;
     std::vector<float> window;     // empty or N
-    DevBuf d_window, d_twiddle;
+    DevBuf d_window;
+    FftPlan plan;              // any fft_size > 0 (fft_any.hip)
     bool has_window = false;
     int upload_window()
     {
@@ -59,8 +60,8 @@ int grhip_fft_vcc_create(grhip_fft_vcc **h, int fft_size, int forward, const flo
     if (!h) return fail(GRHIP_EINVAL, "null argument");
     *h = nullptr;
     if (fft_size <= 0) return fail(GRHIP_ERANGE, "gri_fftw: invalid fft_size");      // gri_fft.cc:104-105
-    if (!fft_size_supported(fft_size))
-        return fail(GRHIP_EINVAL, "fft_size %d: this implementation needs a power of two <= 8192", fft_size);
+    if (!FftPlan::size_ok(fft_size))
+        return fail(GRHIP_EINVAL, "fft_size %d: more than 2^26 points (2^25 when not a power of two)", fft_size);
     if (window_len && !window) return fail(GRHIP_EINVAL, "window is NULL");
     auto *f = new (std::nothrow) grhip_fft_vcc();
     if (!f) return fail(GRHIP_ENOMEM, "alloc");
@@ -68,20 +69,9 @@ int grhip_fft_vcc_create(grhip_fft_vcc **h, int fft_size, int forward, const flo
     // set_window accepts only size 0 or fft_size (gr_fft_vcc.cc:55-64); the ctor ignores the result
     if (window_len == (size_t)fft_size) f->window.assign(window, window + window_len);
     int rc = f->init_device(device);
-    if (!rc) {
-        std::vector<float2> tw((size_t)fft_size);
-        for (int k = 0; k < fft_size; ++k) {
-            double ang = -2.0 * M_PI * (double)k / (double)fft_size;
-            tw[k] = make_float2((float)cos(ang), (float)sin(ang));
-        }
-        rc = f->d_twiddle.reserve(tw.size() * sizeof(float2));
-        if (!rc) {
-            hipError_t e = hipMemcpy(f->d_twiddle.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
-            if (e != hipSuccess) rc = fail(GRHIP_ERUNTIME, "twiddle upload: %s", hipGetErrorString(e));
-        }
-    }
+    if (!rc) rc = f->plan.build(fft_size, f->forward);
     if (!rc) rc = f->upload_window();
-    if (rc) { f->d_window.release(); f->d_twiddle.release(); f->destroy_base(); delete f; return rc; }
+    if (rc) { f->d_window.release(); f->plan.release(); f->destroy_base(); delete f; return rc; }
     *h = f;
     return GRHIP_OK;
 }
@@ -90,7 +80,7 @@ void grhip_fft_vcc_destroy(grhip_fft_vcc *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    h->d_window.release(); h->d_twiddle.release();
+    h->d_window.release(); h->plan.release();
     h->destroy_base();
     delete h;
 }
@@ -113,9 +103,8 @@ int grhip_fft_vcc_work_device(grhip_fft_vcc *h, int noutput_items, const void *d
     if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
     int rc = h->bind();
     if (rc) return rc;
-    rc = launch_fft(h->N, h->forward, h->shift, h->has_window ? h->d_window.as<float>() : nullptr,
-                    h->d_twiddle.as<float2>(), (const float2 *)d_in, (float2 *)d_out, noutput_items,
-                    h->pick(stream));
+    rc = h->plan.exec(h->shift, h->has_window ? h->d_window.as<float>() : nullptr, (const float2 *)d_in, (float2 *)d_out,
+                      noutput_items, h->pick(stream));
     return rc ? rc : noutput_items;
 }
 

@@ -169,8 +169,8 @@ int XlatingCore::build(int device)
         if (rc) return rc;
         const int KS = mf::ksteps_inst(decim, ntaps);
         for (int off = 0; off < 2; ++off) {
-            std::vector<cf> W(mf::THREADS);
-            for (int t = 0; t < mf::THREADS; ++t) {
+            std::vector<cf> W(2 * mf::THREADS);         // 256 staging lanes (fir_mfma_kernel) or 512 (fir_mfma_rs_kernel)
+            for (int t = 0; t < 2 * mf::THREADS; ++t) {
                 double ang = omega * (double)(2 * t - off);
                 W[t] = cf((float)cos(ang), (float)sin(ang));
             }

@@ -13,6 +13,24 @@ int launch_fft(int N, int forward, int shift, const float *window, const float2 
                const float2 *in, float2 *out, long long nvec, hipStream_t st);
 bool fft_size_supported(int N);
 
+// A transform of ANY size the reference's gri_fft_complex accepts (general/gri_fft.cc:97-123), on top of launch_fft:
+// fft_any.hip.  `forward` is fixed at build time for the Bluestein kind (its transformed chirp depends on the sign);
+// exec_pow2 takes either direction (gr_fft_filter_ccc needs both of one power-of-two size).
+struct FftPlan {
+    enum Kind { NATIVE, DIRECT, FOURSTEP, BLUESTEIN };
+    int N = 0, forward = 1;
+    Kind kind = NATIVE;
+    int N1 = 0, N2 = 0;         // FOURSTEP: N = N1 N2
+    int L = 0;                  // BLUESTEIN: convolution length (power of two >= 2N - 1)
+    FftPlan *sub = nullptr;     // BLUESTEIN: the plan of size L
+    DevBuf d_tw, d_tw2, d_thi, d_tlo, d_chirp, d_B, d_s1, d_s2;
+    static bool size_ok(long long N);
+    int build(int N, int forward);
+    void release();
+    int exec(int shift, const float *window, const float2 *in, float2 *out, long long nvec, hipStream_t st);
+    int exec_pow2(int fwd, int shift, const float *window, const float2 *in, float2 *out, long long nvec, hipStream_t st);
+};
+
 struct PfbArgs {
     int M;              // numchans
     int tpf;            // taps per filter

@@ -561,6 +561,390 @@ extern "C" __attribute__((visibility("default"))) int grdbg_set_stamp_buffer_mfm
 }
 #endif
 
+
+// =================================================================================================
+// fir_mfma_rs_kernel -- the same engine with the waves of a workgroup in two ROLES (round 3)
+// =================================================================================================
+// What bounded the kernel above at 0.59 of the HBM peak was bytes in flight: a wave's
+// 17 loads land in the registers it stages from, so they fly for only half a tile period, and the
+// period is the SUM of a wave's phases (stage, matrix, epilogue) beside one partner wave doing the
+// same.  Here one 768-lane workgroup per CU splits the work by role:
+//   * 8 STAGER waves (two per SIMD): loads two tiles ahead into TWO register sets (9 x 16 bytes per
+//     lane each, so a tile's loads fly for about one and a half periods), block-floating-point
+//     maximum, scale / pre-mix / split into the binary16 planes, and the epilogue (demodulator,
+//     stores) of the tile the matrix waves finished a period ago;
+//   * 4 MATRIX waves (one per SIMD): operand reads and MFMAs only, accumulator tiles back into
+//     their own stretch of the planes.  The band matrix (80 VGPRs) lives only here.
+// The planes are double buffered (2 x 4 x 17.3 KB); the two roles meet at two barriers per period:
+//     period p    stagers                                         matrix waves
+//     1st half    loads of tile p;  epilogue of tile p-3;         blocks 0, 1 of tile p-2
+//                 maximum of tile p-1
+//     -- barrier (maxima visible; the epilogue has left buffer (p-1)&1) --
+//     2nd half    stage tile p-1 into buffer (p-1)&1              blocks 2, 3; accumulators -> buffer p&1
+//     -- barrier --
+// A SIMD then holds one MFMA stream and two vector streams instead of two waves that alternate
+// between both.  Every block's epilogue is independent: the demodulator's predecessor of a
+// segment's first output is read from the accumulator tiles in LDS (previous block, or the last
+// block of the segment before) instead of being carried from block to block.
+// Accuracy: a block's 30 MFMAs go to three accumulators (Ah Xh of even / odd k-steps, the two
+// low-half products) that are added once at the end, so an output sees a third of the f32
+// accumulation roundings at half the partial-sum magnitude.
+namespace rs {
+constexpr int NSTG = 8, NMAT = mf::WAVES;
+constexpr int THREADS = 64 * (NSTG + NMAT);
+constexpr int STG_T = 64 * NSTG;
+constexpr int ROUND = 2 * STG_T;        // samples per staging round of the stagers
+constexpr int PD = 2;                   // operand chunks read ahead of their MFMAs
+static_assert(mf::NBLK == 4 && NSTG == 2 * NMAT, "two stagers share a matrix wave's four blocks");
+}  // namespace rs
+
+namespace {
+template <int D, int KS> struct GeoRS {
+    using G = Geo<D, KS>;
+    static constexpr int NI = (G::SP + rs::ROUND - 1) / rs::ROUND;
+    static constexpr int BUF = 4 * G::PL;
+    static constexpr int OFF_ATAN = 2 * BUF;
+    static constexpr int OFF_MISC = OFF_ATAN + 256 * 8;
+    static constexpr int LDS = OFF_MISC + 64;
+    static_assert(rs::ROUND % G::Q == 0, "a staging round must cover whole segment strides");
+    static_assert(2 * (NI - 1) < G::NI, "the stagers' round phasors are every other entry of the 512-sample table");
+    static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+// LDS writes of this wave done, then the workgroup's barrier.  Not __syncthreads(): its fences may
+// wait for the vector-memory counter, which would drain the loads that are meant to stay in flight.
+__device__ __forceinline__ void rs_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+}  // namespace
+
+template <int D, int KS, bool PREMIX, int EPI>
+__global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMfmaArgs a)
+{
+    using G = Geo<D, KS>;
+    using R = GeoRS<D, KS>;
+    constexpr int NI = R::NI, PL = G::PL, LOGQ = G::LOGQ, CB = G::CB, SP = G::SP;
+    constexpr bool DEMOD = EPI == EPI_DEMOD;
+    constexpr bool ROT = EPI == EPI_ROTATE;
+    static_assert(!DEMOD || PREMIX, "the fused demodulator belongs to the pre-mix form");
+    constexpr int NTE = mf::NTE, BLK = mf::BLK, NBLK = mf::NBLK;
+
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    const AtanPairs s_atan{reinterpret_cast<const f32x2 *>(smem + R::OFF_ATAN)};
+    float *wmax = reinterpret_cast<float *>(smem + R::OFF_MISC);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tiles_per_stream = (int)((a.n_out + NTE - 1) / NTE);
+    const unsigned total_tiles = (unsigned)tiles_per_stream * (unsigned)a.n_streams;
+    const unsigned Gd = gridDim.x;
+    // tiles blockIdx.x, blockIdx.x + Gd, ...: q-th tile of this workgroup = blockIdx.x + q Gd
+    const int n_my = (int)((total_tiles - blockIdx.x + Gd - 1) / Gd);
+    const int P = n_my + 3;
+
+    if (w >= rs::NSTG) {
+        // =============================== matrix role ===============================
+        const int mw = w - rs::NSTG;
+        h16x8 Ah[KS], Al[KS];
+        {
+            const h16x8 *Ag = reinterpret_cast<const h16x8 *>(a.A);
+#pragma unroll
+            for (int js = 0; js < KS; ++js) {
+                Ah[js] = Ag[(js * 2 + 0) * 64 + lane];
+                Al[js] = Ag[(js * 2 + 1) * 64 + lane];
+            }
+        }
+        // operand reads: lane = (column, k-group g); column = part * 8 + segment
+        const int col = lane & 15, part = col >> 3, sl = col & 7, g = lane >> 4;
+        const int wu = mw * (mf::WAVE_NEW * D);                         // first sample of the wave's range (a multiple of 32)
+        // byte of sample wu + 32 c + (sl << LOGQ) + 8 g: the lane's part and the chunk's part add up without a carry
+        // into the skew term ((wu + 32 c) mod Q is a multiple of 32 and 8 g < 32)
+        const int rd_lane = part * 2 * PL + 2 * ((sl << LOGQ) + 8 * g) + 32 * sl;
+        auto chunk_off = [&](int c) __attribute__((always_inline)) {
+            const int u = wu + mf::CHUNK * c;
+            return 2 * u + 32 * (u >> LOGQ);
+        };
+        const int scw_u = wu + G::HALO;
+        const int scw_off = 2 * scw_u + 32 * (scw_u >> LOGQ);             // + b * PL for block b
+        const int sc_wr = sl * SCR_SEG + 8 * g + part;                  // + 2 i
+
+        for (int p = 0; p < P; ++p) {
+            const bool act = p >= 2 && p - 2 < n_my;
+            unsigned char *buf = smem + (p & 1) * R::BUF;
+            f32x4 accf[NBLK];
+            // two blocks per half period; the operand chunks of a half are read PD ahead of their use
+            auto half = [&](int h) __attribute__((always_inline)) {
+                constexpr int NS = (NBLK / 2) * KS;
+                h16x8 Bh[rs::PD + 1], Bl[rs::PD + 1];
+                auto ld = [&](int idx) __attribute__((always_inline)) {
+                    const int b = (NBLK / 2) * h + idx / KS, j = idx % KS;
+                    const unsigned char *src = buf + rd_lane + chunk_off(CB * b + j);
+                    Bh[idx % (rs::PD + 1)] = *reinterpret_cast<const h16x8 *>(src);
+                    Bl[idx % (rs::PD + 1)] = *reinterpret_cast<const h16x8 *>(src + PL);
+                };
+#pragma unroll
+                for (int k = 0; k < rs::PD; ++k) ld(k);
+                f32x4 m0, m1, lo;
+#pragma unroll
+                for (int idx = 0; idx < NS; ++idx) {
+                    if (idx + rs::PD < NS) ld(idx + rs::PD);
+                    const int j = idx % KS, sl_ = idx % (rs::PD + 1);
+                    if (j == 0) {
+                        m0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        m1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        lo = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (j & 1) m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh[sl_], m1, 0, 0, 0);
+                    else m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh[sl_], m0, 0, 0, 0);
+                    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bl[sl_], lo, 0, 0, 0);
+                    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[j], Bh[sl_], lo, 0, 0, 0);
+                    if (j == KS - 1) accf[(NBLK / 2) * h + idx / KS] = (m0 + m1) + lo;
+                }
+            };
+            if (act) half(0);
+            rs_barrier();
+            if (act) {
+                half(1);
+                // accumulator layout in ([segment][row][re, im]): block b into plane b of the wave's own stretch
+                // (nobody else reads it: Geo::HALO), read by the stagers after the next barrier
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) {
+                    float *sb = reinterpret_cast<float *>(buf + scw_off + b * PL);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sb[sc_wr + 2 * i] = accf[b][i];
+                }
+            }
+            rs_barrier();
+        }
+        return;
+    }
+
+    // =============================== stager role ===============================
+    const int ts = t;                       // 0 .. STG_T - 1
+    f32x2 wl{1.f, 0.f}, wl1{1.f, 0.f};
+    if (PREMIX) {
+        const float2 v = a.wlane[ts];
+        wl = f32x2{v.x, v.y};
+        wl1 = cmul_pk(wl, f32x2{a.wstep.x, a.wstep.y});
+    }
+    const cfloat_cp stab = (cfloat_cp)a.stab;
+    if (DEMOD) {
+        f32x2 *at = reinterpret_cast<f32x2 *>(smem + R::OFF_ATAN);
+        for (int i = ts; i < 256; i += rs::STG_T) at[i] = f32x2{a.atan_tab[i], a.atan_tab[i + 1]};
+    }
+    // staging store: sample u = 2 ts + ROUND i  ->  byte 2u + 32 (u >> LOGQ) of each plane
+    const int st_off = 4 * ts + 32 * ((2 * ts) >> LOGQ);
+    constexpr int ST_STEP = 2 * rs::ROUND + 32 * (rs::ROUND >> LOGQ);
+    constexpr int OOB = 0x7ffffff0;
+    const int lead = a.off ^ (int)(a.n_lo & 1);
+
+    auto decode = [&](int q, int &s_, int &b_) __attribute__((always_inline)) {
+        const unsigned id = blockIdx.x + (unsigned)q * Gd;
+        b_ = (int)(id / (unsigned)a.n_streams);
+        s_ = (int)(id - (unsigned)b_ * (unsigned)a.n_streams);
+    };
+    auto tile_geom = [&](int s, int b, __amdgpu_buffer_rsrc_t &rsrc, int &voff) __attribute__((always_inline)) {
+        const long long g0 = ((long long)b * NTE - BLK) * D - a.off - a.n_lo + lead;   // tile start relative to the descriptor
+        const float2 *x = a.x + (long long)s * a.x_stride + a.n_lo - lead;
+        const long long bytes = (a.n_in - a.n_lo + lead) * 8;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x), 0, (int)bytes, 0x00020000);
+        voff = (int)(g0 * 8) + 16 * ts;             // negative = before the stream: out of range, zeros
+    };
+
+    // ---- L: the tile's loads, into one of the two register sets ----
+    auto issue_loads = [&](int q, f32x4 (&pf)[NI]) __attribute__((always_inline)) {
+        if (q >= n_my) return;
+        int s, b;
+        decode(q, s, b);
+        __amdgpu_buffer_rsrc_t rsrc; int voff;
+        tile_geom(s, b, rsrc, voff);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int vo = voff + i * (16 * rs::STG_T);
+            if ((i + 1) * rs::ROUND > SP && 2 * ts + i * rs::ROUND >= SP) vo = 0x7ffff000;   // past the tile: no traffic
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
+            pf[i] = __builtin_bit_cast(f32x4, v);
+        }
+    };
+    // ---- M: block floating point, the wave's largest |component| of the tile ----
+    auto tile_max = [&](int q, f32x4 (&pf)[NI]) __attribute__((always_inline)) {
+        if (lead) {
+            // the item in front of a stream that does not start on a 16-byte boundary reads as zero
+            int s, b;
+            decode(q, s, b);
+            if (b == 0) {
+                __amdgpu_buffer_rsrc_t rsrc; int voff;
+                tile_geom(s, b, rsrc, voff);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (voff + i * (16 * rs::STG_T) == 0) { pf[i][0] = 0.f; pf[i][1] = 0.f; }
+            }
+        }
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(pf[i][0]), "v"(pf[i][1]));
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(pf[i][2]), "v"(pf[i][3]));
+        }
+        m = wave_max_nonneg(m);
+        if (lane == 0) wmax[w] = m;
+    };
+    // ---- S: registers -> (scale, pre-mix, split) -> the planes of buffer q & 1 ----
+    auto stage = [&](int q, f32x4 (&pf)[NI], int &kslot) __attribute__((always_inline)) {
+        float mt = wmax[0];
+#pragma unroll
+        for (int i = 1; i < rs::NSTG; ++i) mt = __builtin_fmaxf(mt, wmax[i]);
+        int k = 14 - __builtin_amdgcn_frexp_expf(mt);   // |x| e^{jw} components stay below 2^15
+        k = k > 100 ? 100 : (k < -100 ? -100 : k);
+        kslot = k;
+        const float scale = __builtin_amdgcn_ldexpf(1.0f, k);
+        const f32x2 ws0 = wl * scale, ws1 = wl1 * scale;
+        unsigned char *dst = smem + (q & 1) * R::BUF + st_off;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            f32x2 e0{pf[i][0], pf[i][1]}, e1{pf[i][2], pf[i][3]};
+            if (PREMIX) {
+                const f32x2 S{stab[4 * i], stab[4 * i + 1]};          // e^{jw ROUND i}: every other entry of the table
+                e0 = cmul_pk(e0, cmul_pk(ws0, S));
+                e1 = cmul_pk(e1, cmul_pk(ws1, S));
+            } else {
+                e0 = e0 * scale;
+                e1 = e1 * scale;
+            }
+            const f32x2 re{e0.x, e1.x}, im{e0.y, e1.y};
+            const h16x2 rh = __builtin_convertvector(re, h16x2), ih = __builtin_convertvector(im, h16x2);
+            const h16x2 rlo = split_lo(re, rh), ilo = split_lo(im, ih);
+            if ((i + 1) * rs::ROUND <= SP || 2 * ts + i * rs::ROUND < SP) {
+                unsigned char *d = dst + i * ST_STEP;
+                *reinterpret_cast<h16x2 *>(d) = rh;
+                *reinterpret_cast<h16x2 *>(d + PL) = rlo;
+                *reinterpret_cast<h16x2 *>(d + 2 * PL) = ih;
+                *reinterpret_cast<h16x2 *>(d + 3 * PL) = ilo;
+            }
+        }
+    };
+    // ---- E: two of the four blocks of matrix wave w / 2, from its accumulator tiles in buffer q & 1 ----
+    const int rsl = lane >> 3, r8 = lane & 7;
+    auto epilogue = [&](int q, int kx) __attribute__((always_inline)) {
+        int s, bidx;
+        decode(q, s, bidx);
+        const int mw = w >> 1, b0 = (w & 1) * (NBLK / 2);
+        const int scw_u = mw * (mf::WAVE_NEW * D) + G::HALO;
+        const unsigned char *scr = smem + (q & 1) * R::BUF + 2 * scw_u + 32 * (scw_u >> LOGQ);
+        const float inv_scale = __builtin_amdgcn_ldexpf(1.0f, -kx - a.kexp);
+        // the carry of the previous call, for the stream's first tile (frame of the composite FIR output,
+        // fir_kernels.h), brought into this tile's frame and scale
+        float ypfx = 0.f, ypfy = 0.f;
+        if (DEMOD && bidx == 0 && a.y_prev) {
+            const float2 yp = a.y_prev[s];
+            const float2 vm = a.vtab[BLK - 1];
+            const float2 qq = cmul_fma(yp, make_float2(vm.x, -vm.y));
+            const float sc2 = __builtin_amdgcn_ldexpf(1.0f, kx + a.kexp);
+            ypfx = qq.x * sc2; ypfy = qq.y * sc2;
+        }
+        __amdgpu_buffer_rsrc_t orsrc, grsrc;
+        if (DEMOD) {
+            orsrc = __builtin_amdgcn_make_buffer_rsrc(a.d_out + (long long)s * a.d_stride, 0, (int)(a.n_out * 4), 0x00020000);
+        } else {
+            orsrc = __builtin_amdgcn_make_buffer_rsrc(a.y_out + (long long)s * a.y_stride, 0, (int)(a.n_out * 8), 0x00020000);
+            if (ROT) grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.gtab), 0, (int)(a.n_out * 8), 0x00020000);
+        }
+        const int jt = mw * mf::WAVE_NEW + rsl * mf::SEG_OUT + 2 * r8;       // tile-local index of the lane's first output of block 0
+        const int n_base = bidx * NTE - BLK + jt;                          // its stream index; < 2^28
+        f32x4 yv[NBLK / 2];
+        f32x2 pv[NBLK / 2];
+#pragma unroll
+        for (int bb = 0; bb < NBLK / 2; ++bb) {
+            const int b = b0 + bb;
+            yv[bb] = *reinterpret_cast<const f32x4 *>(scr + b * PL + 4 * (rsl * SCR_SEG + 4 * r8));
+            if (DEMOD) {
+                // predecessor of a segment's first output of the block: row 15 of the block before, or -- block 0 --
+                // of the last block of the segment before (the wave's first segment has none: its block 0 is overlap)
+                const int pb = b == 0 ? NBLK - 1 : b - 1;
+                const int ps = b == 0 ? (rsl > 0 ? rsl - 1 : 0) : rsl;
+                pv[bb] = *reinterpret_cast<const f32x2 *>(scr + pb * PL + 4 * (ps * SCR_SEG + 30));
+            }
+        }
+#pragma unroll
+        for (int bb = 0; bb < NBLK / 2; ++bb) {
+            const int b = b0 + bb;
+            const float y0x = yv[bb][0], y0y = yv[bb][1], y1x = yv[bb][2], y1y = yv[bb][3];
+            const int n = n_base + BLK * b;
+            const bool own = !(b == 0 && rsl == 0) && n >= 0;       // the wave's overlap block stores nothing
+            if (DEMOD) {
+                float px = dpp_row<0x111>(y1x), py = dpp_row<0x111>(y1y);      // row_shr:1: the lane before, same segment
+                const bool from_carry = bidx == 0 && mw == 0 && b == 1 && rsl == 0;    // output 0 of the stream
+                const float qx = from_carry ? ypfx : pv[bb][0], qy = from_carry ? ypfy : pv[bb][1];
+                px = r8 == 0 ? qx : px;
+                py = r8 == 0 ? qy : py;
+                const float d0 = quad_demod_fast(make_float2(y0x, y0y), make_float2(px, py), a.gain, s_atan);
+                const float d1 = quad_demod_fast(make_float2(y1x, y1y), make_float2(y0x, y0y), a.gain, s_atan);
+                const f32x2 dd{d0, d1};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, dd), orsrc, own ? 4 * n : OOB, 0, 0);
+            } else {
+                float2 o0 = make_float2(y0x, y0y), o1 = make_float2(y1x, y1y);
+                if (PREMIX) {
+                    const float4 vv = *reinterpret_cast<const float4 *>(a.vtab + jt + BLK * b);   // e^{-jw j D}
+                    o0 = cmul_fma(o0, make_float2(vv.x, vv.y));
+                    o1 = cmul_fma(o1, make_float2(vv.z, vv.w));
+                }
+                o0.x *= inv_scale; o0.y *= inv_scale; o1.x *= inv_scale; o1.y *= inv_scale;
+                if (ROT) {
+                    const u32x4 gv = __builtin_amdgcn_raw_buffer_load_b128(grsrc, own ? 8 * n : OOB, 0, 0);
+                    const f32x4 gq = __builtin_bit_cast(f32x4, gv);
+                    o0 = cmul_ref(o0, make_float2(gq[0], gq[1]));                   // gr_rotator: z = in * d_phase
+                    o1 = cmul_ref(o1, make_float2(gq[2], gq[3]));
+                }
+                const f32x2 oa{o0.x, o0.y}, ob{o1.x, o1.y};
+                const int so = own ? 8 * n : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oa), orsrc, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), orsrc, so + 8, 0, 0);
+            }
+        }
+        // carry for the next call: the composite FIR output of the stream's last output, computed directly (f32,
+        // composite taps) by the first stager of the workgroup that owns the stream's last tile
+        if (DEMOD && a.y_last && bidx == tiles_per_stream - 1 && w == 0) {
+            const long long item0 = (a.n_out - 1) * D - a.n_lo + lead;       // relative to the stream's descriptor
+            __amdgpu_buffer_rsrc_t xr; int vdummy;
+            tile_geom(s, bidx, xr, vdummy);
+            float sx = 0.f, sy = 0.f;
+            for (int i = lane; i < a.T; i += 64) {
+                const long long it = item0 + i;
+                const int vo = (it < 0 || (lead && it == 0)) ? OOB : (int)(it * 8);
+                const u32x2 xv = __builtin_amdgcn_raw_buffer_load_b64(xr, vo, 0, 0);
+                const f32x2 xf = __builtin_bit_cast(f32x2, xv);
+                const float2 c = a.ctaps[i];
+                sx = __builtin_fmaf(c.x, xf.x, sx); sx = __builtin_fmaf(-c.y, xf.y, sx);
+                sy = __builtin_fmaf(c.x, xf.y, sy); sy = __builtin_fmaf(c.y, xf.x, sy);
+            }
+            sx = wave_sum_f(sx); sy = wave_sum_f(sy);
+            if (lane == 0) a.y_last[s] = make_float2(sx, sy);
+        }
+    };
+
+    // one period: pfL takes the loads of tile p, pfS holds tile p - 1; kslot: the exponent of tile p - 3 on entry
+    // (the epilogue's), of tile p - 1 on exit
+    auto period = [&](int p, f32x4 (&pfL)[NI], f32x4 (&pfS)[NI], int &kslot) __attribute__((always_inline)) {
+        // (the rotate epilogue has loads of its own -- rotator phases -- which the in-order counter would make wait
+        // for the tile loads issued in front of them)
+        if (!ROT) issue_loads(p, pfL);
+        if (p >= 3 && p - 3 < n_my) epilogue(p - 3, kslot);
+        if (ROT) issue_loads(p, pfL);
+        const bool sact = p >= 1 && p - 1 < n_my;
+        if (sact) tile_max(p - 1, pfS);
+        rs_barrier();
+        if (sact) stage(p - 1, pfS, kslot);
+        rs_barrier();
+    };
+    f32x4 pf0[NI], pf1[NI];
+    int k0 = 0, k1 = 0;
+    for (int p = 0; p < P; p += 2) {
+        period(p, pf0, pf1, k1);
+        if (p + 1 < P) period(p + 1, pf1, pf0, k0);
+    }
+}
+
 static int g_mf_cus = 0;
 
 template <int D, int KS, bool PREMIX, int EPI>
@@ -580,6 +964,27 @@ static int launch_mfma_inst(const FirMfmaArgs &a, hipStream_t st)
         g_mf_cus = n > 0 ? n : 256;
     }
     const long long tiles = ((a.n_out + mf::NTE - 1) / mf::NTE) * a.n_streams;
+    // The role-split kernel (one 768-lane workgroup per CU, the whole register file) wherever the FIR has its CUs to
+    // itself; a caller that runs another kernel on the same CUs (max_wg_per_cu = 1: the chain's clock recovery beside
+    // the FIR on shared CUs) keeps the kernel above, which leaves half of every CU free.
+    bool role_split = a.max_wg_per_cu != 1;
+#ifdef GRHIP_DIAG       // diagnostic builds only: GRHIP_MF_RS=0 / 1 forces the choice (A/B runs)
+    if (const char *e = getenv("GRHIP_MF_RS")) role_split = atoi(e) != 0;
+#endif
+    if (role_split) {
+        using R = GeoRS<D, KS>;
+        auto kern_rs = fir_mfma_rs_kernel<D, KS, PREMIX, EPI>;
+        static bool configured_rs = false;
+        if (!configured_rs) {
+            GRHIP_HIP(hipFuncSetAttribute((const void *)kern_rs, hipFuncAttributeMaxDynamicSharedMemorySize, R::LDS));
+            configured_rs = true;
+        }
+        long long grid = a.max_cus > 0 && a.max_cus < g_mf_cus ? a.max_cus : g_mf_cus;
+        if (grid > tiles) grid = tiles;
+        hipLaunchKernelGGL(kern_rs, dim3((unsigned)grid), dim3(rs::THREADS), R::LDS, st, a);
+        GRHIP_HIP(hipGetLastError());
+        return GRHIP_OK;
+    }
     int wgs = (160 * 1024) / (G::LDS + 256);
     if (wgs > 2) wgs = 2;
     if (a.max_wg_per_cu > 0 && wgs > a.max_wg_per_cu) wgs = a.max_wg_per_cu;
