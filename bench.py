@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=10_000_000)
     ap.add_argument("--engine", choices=["fast", "fast_valu"], default="fast",
                     help="fast: GRHIP_MODE_FAST (matrix-core FIR engine); fast_valu: f32 vector FMAs only")
+    ap.add_argument("--chain-captures", type=int, default=2048,
+                    help="captures of the full-chain (configs[3]) measurement that rides in the line at N=1 (0: skip); "
+                         "reduced automatically to what fits the device")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU-only self-test of the N-rank launch path (gloo, a stub step that touches no GPU): "
                          "used by tests/test_bench_launcher.py; the line it prints is labelled as a stub")
@@ -83,9 +86,34 @@ def launch_ranks(a):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
+    # Poll every child: as soon as one exits non-zero the others are ended (terminate, then kill after a grace period)
+    # -- a rank that dies before or during the rendezvous would otherwise leave its siblings waiting in
+    # init_process_group / the broadcast until the distributed timeout.  Rank 0's stdout is read by a thread so that a
+    # full pipe can never block it.
+    import threading
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    codes = [None] * a.gpus
+    failed = False
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if not failed and any(c not in (None, 0) for c in codes):
+            failed = True
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            deadline = time.time() + 10.0
+            while time.time() < deadline and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.02)
+    rd.join(timeout=5.0)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -99,6 +127,8 @@ def launcher_selftest(a):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("GRHIP_SELFTEST_FAIL_RANK") == str(rank):      # tests: this rank dies before the rendezvous
+        raise SystemExit(7)
     os.environ["GRHIP_NO_TORCH_PRELOAD"] = "1"
     if world > 1:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -295,6 +325,98 @@ def cpu_chain_baseline(wl, x_host, proto, lib):
     return out
 
 
+def chain_bench(torch, g, wl, dev, proto, n, want_caps, reps=3):
+    """BASELINE configs[3] / north_star's target shape, driver-visible: the full DMR chain (xlating FIR -> quad demod ->
+    clock_recovery_mm_ff -> slicer -> correlate_access_code, and the 4FSK tail pager_slicer_fb -> unpack_k_bits(2) ->
+    correlator) over a batch of DISTINCT captures (one stream id each, synthesised like the headline's), resident in
+    HBM.  Checked: three captures (first, middle, last) go through the CPU oracle chain -- same symbol count, same number
+    of access-code flags, bit decisions equal but for the few symbols FAST mode may flip (the chain's own parity tests
+    allow 8 per 70 k symbols); the access-code flags of the WHOLE batch are counted on the device against the sync words
+    the generator planted."""
+    c, c4 = wl.CFG2, wl.CFG4
+    free_b, _total = torch.cuda.mem_get_info(dev)
+    nout = n // c["decim"]
+    per_cap = n * 8 + nout * (4 + 4 + 1 + 2 + 1 + 2) + 4096       # input, demod, soft, bits, 4FSK symbols / dibits / bits
+    S = int(min(want_caps, (free_b - (6 << 30)) // per_cap))
+    if S < 1:
+        return {"skipped": "not enough device memory for one capture"}
+    t0 = time.perf_counter()
+    d_in = torch.empty((S, n, 2), dtype=torch.float32, device=dev)
+    first_id = 1000                                               # stream ids 1000 ... 1000 + S - 1
+    CH = 64
+    for k0 in range(0, S, CH):
+        kk = min(CH, S - k0)
+        d_in[k0:k0 + kk] = synth_captures(torch, wl, kk, n, first_id + k0, dev)
+    torch.cuda.synchronize()
+    t_synth = time.perf_counter() - t0
+    ch = g.dmr_chain(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], c4["omega"], c4["gain_omega"],
+                     c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], wl.access_code_string(), c4["threshold"], S, n)
+    st = torch.cuda.Stream(device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    out = {"workload": "full DMR chain: freq_xlating_fir_filter_ccc 256-tap decim 4 -> quadrature_demod_cf -> "
+                       "clock_recovery_mm_ff -> binary_slicer_fb -> correlate_access_code_bb, 10 M-sample captures",
+           "captures": S, "distinct_stream_ids": S, "samples_per_capture": n, "synthesis_s": t_synth,
+           "algorithmic_bytes_per_sample": 8.0 + 1.0 / (c["decim"] * c4["omega"])}
+
+    def timed(bits, stride):
+        for _ in range(2):
+            ch.run_device(d_in, n, n, bits, stride, d_n, st)
+        st.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            ch.run_device(d_in, n, n, bits, stride, d_n, st)
+        e1.record(st)
+        st.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        rate = S * n / ms / 1e3
+        return {"ms_per_batch": ms, "Msamples_per_s": rate,
+                "frac": out["algorithmic_bytes_per_sample"] * rate * 1e6 / 1e9 / HBM_PEAK_GBS}
+
+    d_bits = torch.zeros((S, nout), dtype=torch.uint8, device=dev)
+    out["binary"] = timed(d_bits, nout)
+    # ---- check ----
+    nb = d_n.cpu().numpy()
+    flags_dev = int(((d_bits >> 1) & 1).sum(dtype=torch.int64).item())
+    n_syms_nominal = nout / c4["omega"]
+    planted = len(range(100, int(n_syms_nominal) - 48, c4["sync_period_syms"]))
+    chk = {"access_code_flags_on_device": flags_dev, "sync_words_planted": planted * S,
+           "symbols_min_max": [int(nb.min()), int(nb.max())]}
+    try:
+        po = grhip_loader.import_oracle()
+        lib = "ref" if po.have_ref() else "oracle"
+        worst_flips, caps_checked = 0, []
+        for k in sorted({0, S // 2, S - 1}):
+            xh = d_in[k].cpu().numpy().reshape(-1).view(np.complex64)
+            dem = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], xh, lib=lib)
+            sym, _ = po.chain_mm(c4["omega"], c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], dem)
+            ref = po.CorrelateAccessCode(wl.access_code_string(), c4["threshold"]).work(po.binary_slicer_fb(sym))
+            got = d_bits[k, :int(nb[k])].cpu().numpy()
+            same_len = int(nb[k]) == len(ref)
+            flips = int(np.count_nonzero((got ^ ref[:len(got)]) & 1)) if same_len else -1
+            flags_ok = same_len and int((got >> 1).sum()) == int((ref >> 1).sum())
+            caps_checked.append({"stream_id": first_id + k, "symbols": int(nb[k]), "symbols_oracle": len(ref),
+                                 "bit_flips_vs_oracle": flips, "access_code_flags_equal": bool(flags_ok)})
+            worst_flips = max(worst_flips, flips if flips >= 0 else 1 << 30)
+        chk["captures_through_the_cpu_oracle"] = caps_checked
+        chk["oracle_kind"] = "reference SSE dot product + rotator + atan (oracle/_ref)" if lib == "ref" else "generic-order port"
+        chk["ok"] = bool(all(cc["symbols"] == cc["symbols_oracle"] and cc["access_code_flags_equal"] for cc in caps_checked)
+                         and worst_flips <= 32 and abs(flags_dev - planted * S) <= 2 * S)
+    except Exception as e:  # pragma: no cover
+        chk["error"] = str(e)
+        chk["ok"] = False
+    out["check"] = chk
+    del d_bits
+    # ---- 4FSK tail ----
+    ch.set_four_level(True, 0.001)
+    d_bits2 = torch.zeros((S, 2 * nout), dtype=torch.uint8, device=dev)
+    out["four_level"] = timed(d_bits2, 2 * nout)
+    out["four_level"]["tail"] = "pager_slicer_fb(alpha 0.001) -> unpack_k_bits_bb(2) -> correlate_access_code_bb, two items per symbol"
+    del ch, d_bits2, d_in
+    torch.cuda.synchronize()
+    return out
+
+
 def measured_traffic(kernel, captures, samples, launches_per_step):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
     passes (profiles/traffic.json: FETCH_SIZE doubled per the gfx950 correction for
@@ -410,7 +532,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    my_elapsed = elapsed
     elapsed = gd.max_over_ranks(elapsed, dist, dev)
+    per_rank_ms = [my_elapsed / a.steps * 1e3]
+    if world > 1:                                   # a straggler shows in the line (every rank's own clock)
+        allr = [None] * world
+        dist.all_gather_object(allr, my_elapsed / a.steps * 1e3)
+        per_rank_ms = allr
 
     # the same step on the vector-FMA engine (the north star's "no MFMA" form), reported beside the headline: a few
     # untimed steps for the clocks, then the same K steps under HIP events
@@ -451,7 +579,10 @@ def main():
             "metric": "Msamples/s through FIR->demod chain @256 taps",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("f32 (FIR operands split into two binary16 halves on the matrix cores, f32 accumulation; demodulator f32)"
+                      if a.engine == "fast" else "f32"),
+            "data": "synthetic", "per_rank_ms_per_step": per_rank_ms,
             "config": {"workload": "freq_xlating_fir_filter_ccc 256-tap decim=4 + quadrature_demod_cf, "
                                    "10 MS/s synthetic 4FSK IQ", "captures_per_gpu_per_step": B,
                        "samples_per_capture": n, "sharding": "independent captures per rank, "
@@ -474,6 +605,16 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, x0_host[: a.cpu_samples], proto)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        if world == 1 and a.chain_captures > 0 and not a.per_capture_launch:
+            del buf, out
+            torch.cuda.empty_cache()
+            try:
+                res["chain"] = chain_bench(torch, g, wl, dev, proto, n, a.chain_captures)
+                cb = res.get("cpu_baseline", {}).get("chain", {}).get("serial_1_thread", {}).get("value")
+                if cb and "binary" in res["chain"]:
+                    res["chain"]["gpu_over_cpu_1_thread"] = res["chain"]["binary"]["Msamples_per_s"] / cb
+            except Exception as e:  # pragma: no cover
+                res["chain"] = {"error": str(e)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1058,6 +1058,12 @@ class dmr_chain(_Block):
         L.grhip_dmr_chain_set_captures_per_wave.argtypes = [C.c_void_p, C.c_int]
         _check(L.grhip_dmr_chain_set_captures_per_wave(self._h, int(captures)))
 
+    def set_max_symbols(self, max_symbols):
+        """noutput_items of the clock recovery per capture (0: unbounded)"""
+        L = lib()
+        L.grhip_dmr_chain_set_max_symbols.argtypes = [C.c_void_p, C.c_size_t]
+        _check(L.grhip_dmr_chain_set_max_symbols(self._h, int(max_symbols)))
+
     def set_four_level(self, enable, pager_alpha=0.001):
         """4FSK tail: pager.slicer_fb(alpha) -> unpack_k_bits_bb(2) -> correlator; two output items per symbol"""
         L = lib()

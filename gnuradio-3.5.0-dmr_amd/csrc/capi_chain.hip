@@ -59,6 +59,7 @@ struct grhip_dmr_chain : HandleBase {
     hipStream_t st_mm8 = nullptr, st_fir8 = nullptr;
     int fir8_cus = 0;
     int captures_per_wave = 0;        // 0: by batch size; 1 / 8: forced (grhip_dmr_chain_set_captures_per_wave)
+    size_t max_symbols = 0;           // 0: none (grhip_dmr_chain_set_max_symbols)
     bool mm_rows() const { return captures_per_wave ? captures_per_wave == 8 : S >= GRHIP_MM_ROWS_MIN; }
     static constexpr int PIPE_CHUNKS = GRHIP_PIPE_CHUNKS;
     // 4FSK tail (grhip_dmr_chain_set_four_level): pager_slicer_fb -> unpack_k_bits(2) in front of the correlator
@@ -175,6 +176,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
     hipStream_t st = h->pick(stream);
     const size_t S = (size_t)h->S;
     const long long n_out = (long long)(n_samples / h->core.decim);
+    const int mm_nout = (int)(h->max_symbols && (long long)h->max_symbols < n_out ? (long long)h->max_symbols : n_out);
     if (n_out <= 0) { GRHIP_HIP(hipMemsetAsync(d_nbits, 0, S * sizeof(int), st)); return GRHIP_OK; }
     if ((size_t)n_out * (h->four_level ? 2 : 1) > bits_stride) return fail(GRHIP_EINVAL, "bits_stride too small");
 
@@ -231,7 +233,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
                 GRHIP_HIP(hipStreamWaitEvent(st_side, h->ev_fir[c], 0));
             }
             // 2) M&M clock recovery, one wavefront per stream, over what has been demodulated so far
-            rc = launch_mm(h->d_mm.as<MMState>(), h->S, (int)n_out, (int)(o0 + len), h->d_demod.as<float>(),
+            rc = launch_mm(h->d_mm.as<MMState>(), h->S, mm_nout, (int)(o0 + len), h->d_demod.as<float>(),
                            (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
                            h->d_counts.as<int>(), h->tabs->mmse_rev, st_mm, 1, rows);
             if (rc) { h->core.mf_wg_cap = 0; h->core.mf_cu_cap = 0; return rc; }
@@ -260,7 +262,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
             if (rc) return rc;
         }
         // 2) M&M clock recovery, one wavefront per stream
-        rc = launch_mm(h->d_mm.as<MMState>(), h->S, (int)n_out, (int)n_out, h->d_demod.as<float>(),
+        rc = launch_mm(h->d_mm.as<MMState>(), h->S, mm_nout, (int)n_out, h->d_demod.as<float>(),
                        (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
                        h->d_counts.as<int>(), h->tabs->mmse_rev, st, 0, h->mm_rows() ? 512 : 0);
         if (rc) return rc;
@@ -316,6 +318,13 @@ int grhip_dmr_chain_set_captures_per_wave(grhip_dmr_chain *h, int captures)
 {
     if (!h || !(captures == 0 || captures == 1 || captures == 8)) return fail(GRHIP_EINVAL, "captures per wave: 0 (by batch size), 1 or 8");
     h->captures_per_wave = captures;
+    return GRHIP_OK;
+}
+
+int grhip_dmr_chain_set_max_symbols(grhip_dmr_chain *h, size_t max_symbols)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    h->max_symbols = max_symbols;
     return GRHIP_OK;
 }
 

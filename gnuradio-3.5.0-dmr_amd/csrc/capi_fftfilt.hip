@@ -17,7 +17,8 @@ struct grhip_fft_filter_ccc : HandleBase {
     int decim = 1, ntaps = 0, fftsize = 0, nsamples = 0;
     std::vector<std::complex<float>> new_taps;
     bool updated = false;
-    DevBuf d_twiddle, d_xformed, d_tail, d_a, d_b;
+    DevBuf d_xformed, d_tail, d_a, d_b;
+    FftPlan plan;              // the fftsize-point transform, both directions (four-step form above 8192 points)
     // fused overlap-save path (ntaps <= FUSED_MAX_TAPS): 4096-point blocks, see fftfilt4096_kernel
     bool fused = false;
     int L = 0, fold = 0;             // full-rate outputs per block (a multiple of the decimation); folded inverse
@@ -30,27 +31,18 @@ struct grhip_fft_filter_ccc : HandleBase {
         ntaps = (int)n;
         fftsize = (int)(2 * pow(2.0, ceil(log((double)ntaps) / log(2.0))));
         nsamples = fftsize - ntaps + 1;
-        if (!fft_size_supported(fftsize))
-            return fail(GRHIP_EINVAL, "fft_filter_ccc: %d taps need an FFT of %d points (this implementation: <= 8192)",
-                        ntaps, fftsize);
-        std::vector<float2> tw((size_t)fftsize), H((size_t)fftsize);
-        for (int k = 0; k < fftsize; ++k) {
-            double ang = -2.0 * M_PI * (double)k / (double)fftsize;
-            tw[k] = make_float2((float)cos(ang), (float)sin(ang));
-        }
-        // forward transform of the scaled, zero-padded taps (double DFT, rounded once)
+        if (ntaps > (1 << 25) || !FftPlan::size_ok(fftsize))
+            return fail(GRHIP_EINVAL, "fft_filter_ccc: %d taps need an FFT of more than 2^26 points", ntaps);
+        int rcp = plan.build(fftsize, 1);
+        if (rcp) return rcp;
+        // forward transform of the scaled, zero-padded taps (double, rounded once)
         const float scale = 1.0 / fftsize;                                              // :76
-        std::vector<std::complex<double>> t((size_t)ntaps);
+        std::vector<std::complex<double>> t((size_t)fftsize, std::complex<double>(0, 0));
         for (int i = 0; i < ntaps; ++i)
             t[i] = std::complex<double>((double)(taps[i].real() * scale), (double)(taps[i].imag() * scale));
-        for (int k = 0; k < fftsize; ++k) {
-            std::complex<double> acc(0, 0);
-            for (int i = 0; i < ntaps; ++i) {
-                double ang = -2.0 * M_PI * (double)(((long long)k * i) % fftsize) / (double)fftsize;
-                acc += t[i] * std::complex<double>(cos(ang), sin(ang));
-            }
-            H[k] = make_float2((float)acc.real(), (float)acc.imag());
-        }
+        host_fft_pow2(t, -1);
+        std::vector<float2> H((size_t)fftsize);
+        for (int k = 0; k < fftsize; ++k) H[k] = make_float2((float)t[k].real(), (float)t[k].imag());
         fused = ntaps <= OLS_MAX_TAPS && ((OLS_N - (ntaps - 1)) / decim) >= 1;
         if (fused) {
             int rc4 = ols_build((const float *)taps, ntaps, decim, d_tw4096, d_H4096, &L, &fold);
@@ -63,18 +55,16 @@ struct grhip_fft_filter_ccc : HandleBase {
             hist_cur = 0;
         }
         const size_t tail_items = (size_t)(ntaps > 1 ? ntaps - 1 : 1);
-        int rc = d_twiddle.reserve(tw.size() * sizeof(float2));
-        if (!rc) rc = d_xformed.reserve(H.size() * sizeof(float2));
+        int rc = d_xformed.reserve(H.size() * sizeof(float2));
         if (!rc) rc = d_tail.reserve(tail_items * sizeof(float2));
         if (rc) return rc;
-        GRHIP_HIP(hipMemcpy(d_twiddle.p, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
         GRHIP_HIP(hipMemcpy(d_xformed.p, H.data(), H.size() * sizeof(float2), hipMemcpyHostToDevice));
         GRHIP_HIP(hipMemset(d_tail.p, 0, tail_items * sizeof(float2)));                 // tail cleared (:69-71)
         return GRHIP_OK;
     }
     void release_all()
     {
-        d_twiddle.release(); d_xformed.release(); d_tail.release(); d_a.release(); d_b.release();
+        plan.release(); d_xformed.release(); d_tail.release(); d_a.release(); d_b.release();
         d_tw4096.release(); d_H4096.release(); d_hist[0].release(); d_hist[1].release();
     }
 };
@@ -153,9 +143,9 @@ int grhip_fft_filter_ccc_work_device(grhip_fft_filter_ccc *h, int noutput_items,
     float2 *A = h->d_a.as<float2>(), *B = h->d_b.as<float2>();
     const int tailsize = h->ntaps - 1;
     if ((rc = launch_fftfilt_pack((const float2 *)d_in, A, h->nsamples, h->fftsize, nblk, st))) return rc;
-    if ((rc = launch_fft(h->fftsize, 1, 0, nullptr, h->d_twiddle.as<float2>(), A, B, nblk, st))) return rc;
+    if ((rc = h->plan.exec_pow2(1, 0, nullptr, A, B, nblk, st))) return rc;
     if ((rc = launch_fftfilt_mul(B, h->d_xformed.as<float2>(), h->fftsize, nblk, st))) return rc;
-    if ((rc = launch_fft(h->fftsize, 0, 0, nullptr, h->d_twiddle.as<float2>(), B, A, nblk, st))) return rc;
+    if ((rc = h->plan.exec_pow2(0, 0, nullptr, B, A, nblk, st))) return rc;
     if ((rc = launch_fftfilt_ola(A, h->d_tail.as<float2>(), (float2 *)d_out, noutput_items, h->decim, h->nsamples,
                                  h->fftsize, tailsize, st)))
         return rc;

@@ -311,6 +311,10 @@ mm_rows_kernel(MMState *__restrict__ state, int n_streams, int noutput_items, in
                 if (l < c) y[oo + l] = obuf;
                 oo += c;
                 if (!(oo < noutput_items)) { fin = true; inw = false; }
+                // K was chosen before this loop: once a capture has fewer than 8 outputs of room left, go back for
+                // single symbols (eight more steps would store past y[noutput_items - 1] and leave oo beyond the limit
+                // the reference stops at, .cc:113)
+                if (K != 1 && noutput_items - oo < MMR_RL) inw = false;
                 inw = __all(inw);
             } while (inw);
             // left the ring, or the stream: .cc:113 (ii < ni), and the reference would read before its buffer at ii < 0

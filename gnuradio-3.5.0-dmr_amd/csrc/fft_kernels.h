@@ -31,6 +31,12 @@ struct FftPlan {
     int exec_pow2(int fwd, int shift, const float *window, const float2 *in, float2 *out, long long nvec, hipStream_t st);
 };
 
+}  // namespace grhip
+#include <complex>
+namespace grhip {
+// in-place radix-2 transform on the host, in double (set-up work: transformed taps, Bluestein's chirp); sign -1 = forward
+void host_fft_pow2(std::vector<std::complex<double>> &a, int sign);
+
 struct PfbArgs {
     int M;              // numchans
     int tpf;            // taps per filter

@@ -125,6 +125,20 @@ __device__ __forceinline__ h16x2 split_lo(f32x2 x, h16x2 hi)
     return __builtin_bit_cast(h16x2, lo);
 }
 
+// both halves of a scaled pair in four mixed-precision FMAs: hi = (binary16)(x s), lo = (binary16)(x s - hi); s is a
+// power of two, so x s is exact inside the FMA and each half is rounded once (the same values as a product, a
+// conversion and split_lo, three instructions fewer per pair)
+__device__ __forceinline__ void split_scaled(float x0, float x1, float s, h16x2 &hi, h16x2 &lo)
+{
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+    hi = __builtin_bit_cast(h16x2, h);
+    lo = __builtin_bit_cast(h16x2, l);
+}
+
 // Diagnostic build only (-DGRHIP_STAMP, `make stamp`): per-wave time shares of the phases of a
 // tile (100 MHz real-time counter), written to a buffer of their own (never to an output).
 #ifdef GRHIP_STAMP
@@ -139,9 +153,14 @@ __device__ __forceinline__ unsigned long long mf_stamp_now()
 }
 #define MF_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = mf_stamp_now(), st_begin = st_last
 #define MF_STAMP(k) do { unsigned long long n__ = mf_stamp_now(); st_acc[k] += n__ - st_last; st_last = n__; } while (0)
+#define MF_STAMP_OUT(nwaves) do { if ((threadIdx.x & 63) == 0 && g_mf_stamp_buf) { \
+        unsigned long long *o__ = g_mf_stamp_buf + ((size_t)blockIdx.x * (nwaves) + (threadIdx.x >> 6)) * 10; \
+        for (int k__ = 0; k__ < 8; ++k__) o__[k__] = st_acc[k__]; \
+        o__[8] = st_begin; o__[9] = mf_stamp_now(); } } while (0)
 #else
 #define MF_STAMP_DECL
 #define MF_STAMP(k)
+#define MF_STAMP_OUT(nwaves)
 #endif
 
 struct AtanPairs {
@@ -272,6 +291,17 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                 asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(pf[i][2]), "v"(pf[i][3]));
             }
             m = wave_max_nonneg(m);
+            if (!(m < __builtin_inff())) {          // an Inf / NaN sample: the scale comes from the finite ones (see fir_mfma_rs_kernel)
+                float mf = 0.f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float av = __builtin_fabsf(pf[i][e]);
+                        mf = av < __builtin_inff() ? __builtin_fmaxf(mf, av) : mf;
+                    }
+                m = wave_max_nonneg(mf);
+            }
             if (lane == 0) wmax[w] = m;
             if (a.sched && t == 0) sched_slot[0] = nn_q + 2u * Gd;    // the queue's answer for the tile after next
         }
@@ -594,7 +624,10 @@ constexpr int NSTG = 8, NMAT = mf::WAVES;
 constexpr int THREADS = 64 * (NSTG + NMAT);
 constexpr int STG_T = 64 * NSTG;
 constexpr int ROUND = 2 * STG_T;        // samples per staging round of the stagers
-constexpr int PD = 2;                   // operand chunks read ahead of their MFMAs
+#ifndef GRHIP_RS_PD
+#define GRHIP_RS_PD 2
+#endif
+constexpr int PD = GRHIP_RS_PD;         // operand chunks read ahead of their MFMAs
 static_assert(mf::NBLK == 4 && NSTG == 2 * NMAT, "two stagers share a matrix wave's four blocks");
 }  // namespace rs
 
@@ -646,6 +679,9 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
     if (w >= rs::NSTG) {
         // =============================== matrix role ===============================
         const int mw = w - rs::NSTG;
+#if defined(GRHIP_RS_PRIO) && GRHIP_RS_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
         h16x8 Ah[KS], Al[KS];
         {
             const h16x8 *Ag = reinterpret_cast<const h16x8 *>(a.A);
@@ -669,6 +705,7 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         const int scw_off = 2 * scw_u + 32 * (scw_u >> LOGQ);             // + b * PL for block b
         const int sc_wr = sl * SCR_SEG + 8 * g + part;                  // + 2 i
 
+        MF_STAMP_DECL;
         for (int p = 0; p < P; ++p) {
             const bool act = p >= 2 && p - 2 < n_my;
             unsigned char *buf = smem + (p & 1) * R::BUF;
@@ -702,8 +739,11 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
                     if (j == KS - 1) accf[(NBLK / 2) * h + idx / KS] = (m0 + m1) + lo;
                 }
             };
+            MF_STAMP(7);
             if (act) half(0);
+            MF_STAMP(0);
             rs_barrier();
+            MF_STAMP(3);
             if (act) {
                 half(1);
                 // accumulator layout in ([segment][row][re, im]): block b into plane b of the wave's own stretch
@@ -715,20 +755,35 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
                     for (int i = 0; i < 4; ++i) sb[sc_wr + 2 * i] = accf[b][i];
                 }
             }
+            MF_STAMP(4);
             rs_barrier();
+            MF_STAMP(5);
         }
+        MF_STAMP_OUT(rs::NSTG + rs::NMAT);
         return;
     }
 
     // =============================== stager role ===============================
     const int ts = t;                       // 0 .. STG_T - 1
-    f32x2 wl{1.f, 0.f}, wl1{1.f, 0.f};
+    MF_STAMP_DECL;
+#if defined(GRHIP_RS_PRIO) && GRHIP_RS_PRIO == 1
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    // pre-mix phasors of the lane's two samples of every staging round, e^{jw(2 ts + ROUND i - off)} and the next one:
+    // tile independent, registers for the whole launch (the tile's scale goes into the binary16 conversion instead)
+    f32x2 W0[NI], W1[NI];
+    const cfloat_cp stab = (cfloat_cp)a.stab;
     if (PREMIX) {
         const float2 v = a.wlane[ts];
-        wl = f32x2{v.x, v.y};
-        wl1 = cmul_pk(wl, f32x2{a.wstep.x, a.wstep.y});
+        const f32x2 wl{v.x, v.y};
+        const f32x2 wl1 = cmul_pk(wl, f32x2{a.wstep.x, a.wstep.y});
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const f32x2 S{stab[4 * i], stab[4 * i + 1]};          // e^{jw ROUND i}: every other entry of the 512-sample table
+            W0[i] = cmul_pk(wl, S);
+            W1[i] = cmul_pk(wl1, S);
+        }
     }
-    const cfloat_cp stab = (cfloat_cp)a.stab;
     if (DEMOD) {
         f32x2 *at = reinterpret_cast<f32x2 *>(smem + R::OFF_ATAN);
         for (int i = ts; i < 256; i += rs::STG_T) at[i] = f32x2{a.atan_tab[i], a.atan_tab[i + 1]};
@@ -751,9 +806,21 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x), 0, (int)bytes, 0x00020000);
         voff = (int)(g0 * 8) + 16 * ts;             // negative = before the stream: out of range, zeros
     };
+    // the item in front of a stream that does not start on a 16-byte boundary (lead = 1: the descriptor starts one
+    // item early) reads as zero: it sits in the first tile's round 0 (the tile starts BLK D + off + n_lo - lead < ROUND
+    // samples before the stream's first item) and is dropped where the values are used, not in the registers
+    static_assert(BLK * D + 1 + 32 * KS < rs::ROUND, "the stream's first item lies in round 0 of its first tile");
+    auto lead_item_here = [&](int q) __attribute__((always_inline)) -> bool {
+        if (!lead) return false;
+        int s, b;
+        decode(q, s, b);
+        __amdgpu_buffer_rsrc_t rsrc; int voff;
+        tile_geom(s, b, rsrc, voff);
+        return b == 0 && voff == 0;
+    };
 
-    // ---- L: the tile's loads, into one of the two register sets ----
-    auto issue_loads = [&](int q, f32x4 (&pf)[NI]) __attribute__((always_inline)) {
+    // ---- L: the tile's loads, rounds [i0, i1), into one of the two register sets ----
+    auto issue_loads = [&](int q, f32x4 (&pf)[NI], int i0, int i1) __attribute__((always_inline)) {
         if (q >= n_my) return;
         int s, b;
         decode(q, s, b);
@@ -761,6 +828,7 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         tile_geom(s, b, rsrc, voff);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
+            if (i < i0 || i >= i1) continue;
             int vo = voff + i * (16 * rs::STG_T);
             if ((i + 1) * rs::ROUND > SP && 2 * ts + i * rs::ROUND >= SP) vo = 0x7ffff000;   // past the tile: no traffic
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
@@ -769,28 +837,32 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
     };
     // ---- M: block floating point, the wave's largest |component| of the tile ----
     auto tile_max = [&](int q, f32x4 (&pf)[NI]) __attribute__((always_inline)) {
-        if (lead) {
-            // the item in front of a stream that does not start on a 16-byte boundary reads as zero
-            int s, b;
-            decode(q, s, b);
-            if (b == 0) {
-                __amdgpu_buffer_rsrc_t rsrc; int voff;
-                tile_geom(s, b, rsrc, voff);
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    if (voff + i * (16 * rs::STG_T) == 0) { pf[i][0] = 0.f; pf[i][1] = 0.f; }
-            }
-        }
+        const bool lz = lead_item_here(q);
         float m = 0.f;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(pf[i][0]), "v"(pf[i][1]));
+            const float x0 = (i == 0 && lz) ? 0.f : pf[i][0], x1 = (i == 0 && lz) ? 0.f : pf[i][1];
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(x0), "v"(x1));
             asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(pf[i][2]), "v"(pf[i][3]));
         }
         m = wave_max_nonneg(m);
+        if (!(m < __builtin_inff())) {
+            // an Inf / NaN sample (rare; the branch is wave-uniform): the scale comes from the finite samples, so that
+            // the damage stays where the reference has it -- the outputs whose window holds the sample (and, here, the
+            // rest of their 16-output block: zeros of the band matrix times Inf) -- instead of flushing the whole tile
+            float mf = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float av = __builtin_fabsf(pf[i][e]);
+                    if (!(i == 0 && e < 2 && lz)) mf = av < __builtin_inff() ? __builtin_fmaxf(mf, av) : mf;
+                }
+            m = wave_max_nonneg(mf);
+        }
         if (lane == 0) wmax[w] = m;
     };
-    // ---- S: registers -> (scale, pre-mix, split) -> the planes of buffer q & 1 ----
+    // ---- S: registers -> (pre-mix, scale, split) -> the planes of buffer q & 1 ----
     auto stage = [&](int q, f32x4 (&pf)[NI], int &kslot) __attribute__((always_inline)) {
         float mt = wmax[0];
 #pragma unroll
@@ -799,22 +871,19 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         k = k > 100 ? 100 : (k < -100 ? -100 : k);
         kslot = k;
         const float scale = __builtin_amdgcn_ldexpf(1.0f, k);
-        const f32x2 ws0 = wl * scale, ws1 = wl1 * scale;
+        const bool lz = lead_item_here(q);
         unsigned char *dst = smem + (q & 1) * R::BUF + st_off;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             f32x2 e0{pf[i][0], pf[i][1]}, e1{pf[i][2], pf[i][3]};
+            if (i == 0 && lz) e0 = f32x2{0.f, 0.f};
             if (PREMIX) {
-                const f32x2 S{stab[4 * i], stab[4 * i + 1]};          // e^{jw ROUND i}: every other entry of the table
-                e0 = cmul_pk(e0, cmul_pk(ws0, S));
-                e1 = cmul_pk(e1, cmul_pk(ws1, S));
-            } else {
-                e0 = e0 * scale;
-                e1 = e1 * scale;
+                e0 = cmul_pk(e0, W0[i]);
+                e1 = cmul_pk(e1, W1[i]);
             }
-            const f32x2 re{e0.x, e1.x}, im{e0.y, e1.y};
-            const h16x2 rh = __builtin_convertvector(re, h16x2), ih = __builtin_convertvector(im, h16x2);
-            const h16x2 rlo = split_lo(re, rh), ilo = split_lo(im, ih);
+            h16x2 rh, rlo, ih, ilo;
+            split_scaled(e0.x, e1.x, scale, rh, rlo);
+            split_scaled(e0.y, e1.y, scale, ih, ilo);
             if ((i + 1) * rs::ROUND <= SP || 2 * ts + i * rs::ROUND < SP) {
                 unsigned char *d = dst + i * ST_STEP;
                 *reinterpret_cast<h16x2 *>(d) = rh;
@@ -923,19 +992,34 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         }
     };
 
-    // one period: pfL takes the loads of tile p, pfS holds tile p - 1; kslot: the exponent of tile p - 3 on entry
-    // (the epilogue's), of tile p - 1 on exit
+    // one period: pfL takes the loads of tile p, pfS holds tile p - 1 (complete: every period ends with the wave's
+    // vector-memory counter at zero); kslot: the exponent of tile p - 3 on entry (the epilogue's), of tile p - 1 on exit.
+    // The loads fly for the whole period -- behind the epilogue, the maximum and the staging of the other register
+    // set -- and are waited for ONCE, at its end, with a wait the compiler's counter bookkeeping understands
+    // (__builtin_amdgcn_s_waitcnt): a set that is loaded in one trip of the loop and used in the next makes hipcc 7.2
+    // wait for "all but the 8 youngest" operations at the first use, i.e. for the loads just issued.
+    constexpr int LA = (NI + 1) / 2;            // rounds requested at the period's start, the rest behind the epilogue
     auto period = [&](int p, f32x4 (&pfL)[NI], f32x4 (&pfS)[NI], int &kslot) __attribute__((always_inline)) {
+        MF_STAMP(7);
         // (the rotate epilogue has loads of its own -- rotator phases -- which the in-order counter would make wait
         // for the tile loads issued in front of them)
-        if (!ROT) issue_loads(p, pfL);
+        if (!ROT) issue_loads(p, pfL, 0, LA);
+        MF_STAMP(0);
         if (p >= 3 && p - 3 < n_my) epilogue(p - 3, kslot);
-        if (ROT) issue_loads(p, pfL);
+        if (ROT) issue_loads(p, pfL, 0, LA);
+        issue_loads(p, pfL, LA, NI);
+        MF_STAMP(1);
         const bool sact = p >= 1 && p - 1 < n_my;
         if (sact) tile_max(p - 1, pfS);
+        MF_STAMP(2);
         rs_barrier();
+        MF_STAMP(3);
         if (sact) stage(p - 1, pfS, kslot);
+        MF_STAMP(4);
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): tile p has landed (and the epilogue's stores are out)
+        MF_STAMP(6);
         rs_barrier();
+        MF_STAMP(5);
     };
     f32x4 pf0[NI], pf1[NI];
     int k0 = 0, k1 = 0;
@@ -943,6 +1027,7 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         period(p, pf0, pf1, k1);
         if (p + 1 < P) period(p + 1, pf1, pf0, k0);
     }
+    MF_STAMP_OUT(rs::NSTG + rs::NMAT);
 }
 
 static int g_mf_cus = 0;

@@ -482,9 +482,11 @@ GRHIP_API int grhip_correlate_access_code_bb_work_device(grhip_correlate_access_
  *   general/gr_fft_vcc.h:41-59, general/gr_fft_vcc.cc:34-64,
  *   general/gr_fft_vcc_fftw.cc:39-103 (FFTW3f c2c, unnormalised)
  * items are vectors of fft_size complex.  window: NULL/0 or fft_size floats.
- * GRHIP_ERANGE if fft_size <= 0 (general/gri_fft.cc:104-105);
- * GRHIP_EINVAL if fft_size is not a power of two <= 65536 (device limit of
- * this implementation).
+ * GRHIP_ERANGE if fft_size <= 0 (general/gri_fft.cc:104-105).  Every other size the
+ * reference hands to FFTW is taken (general/gri_fft.cc:97-123): powers of two up to 8192
+ * by the radix-16 register kernels, larger ones (up to 2^26) in four-step form, sizes that
+ * are not a power of two by a direct DFT (<= 128) or Bluestein's chirp convolution (up to
+ * 2^25); beyond that GRHIP_EINVAL (a handle's work buffers are sized for 2^26 points).
  * ====================================================================== */
 typedef struct grhip_fft_vcc grhip_fft_vcc;
 GRHIP_API int grhip_fft_vcc_create(grhip_fft_vcc **h, int fft_size, int forward, const float *window,
@@ -505,7 +507,8 @@ GRHIP_API int grhip_fft_vcc_work_device(grhip_fft_vcc *h, int noutput_items, con
  * 1/fftsize, tail carried between blocks and calls.  gr_sync_decimator, history 1.
  * noutput_items must be a multiple of nsamples (the reference asserts it, .cc:121).
  * set_taps takes effect at the next work call, which returns 0 (.cc:113-118) and clears
- * the tail (generic.cc:69-71).  ntaps <= 4096 (fftsize <= 8192).
+ * the tail (generic.cc:69-71).  Any tap count up to 2^25 (fftsize <= 2^26; beyond 4096 taps the
+ * transforms run in four-step form).
  * ====================================================================== */
 typedef struct grhip_fft_filter_ccc grhip_fft_filter_ccc;
 GRHIP_API int grhip_fft_filter_ccc_create(grhip_fft_filter_ccc **h, int decimation, const float *taps,
@@ -583,6 +586,10 @@ GRHIP_API int grhip_dmr_chain_set_mode(grhip_dmr_chain *h, int mode);
  * captures, where the loop then leaves the FIR its full grid); 0 = chosen by n_streams (the default).  Results are
  * identical (both forms are bit-exact on their input). */
 GRHIP_API int grhip_dmr_chain_set_captures_per_wave(grhip_dmr_chain *h, int captures);
+/* Upper bound on the symbols the clock recovery produces per capture: the noutput_items of its general_work
+ * (digital_clock_recovery_mm_ff.cc:113, `oo < noutput_items`); 0 = no bound but the output rows (the default).
+ * A capture stops at exactly that many symbols, whichever form of the loop runs. */
+GRHIP_API int grhip_dmr_chain_set_max_symbols(grhip_dmr_chain *h, size_t max_symbols);
 /* 4FSK tail: with enable != 0 the symbols go through pager_slicer_fb(alpha)
  * (gr-pager/lib/pager_slicer_fb.cc:47-84) -> gr_unpack_k_bits_bb(2) (general/gr_unpack_k_bits_bb.cc:64-69) ->
  * the access-code correlator instead of the binary slicer: both bits of every symbol, most significant first.

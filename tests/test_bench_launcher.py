@@ -49,6 +49,18 @@ def test_failing_rank_fails_the_run():
     assert r.returncode != 0
 
 
+def test_one_failing_rank_ends_the_others_promptly():
+    """rank 1 dies before the rendezvous while rank 0 sits in init_process_group -- the launcher must notice,
+    end rank 0 and exit non-zero within seconds, not after the distributed timeout"""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--captures", "2", "--launcher-selftest"],
+             {"GRHIP_SELFTEST_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode != 0
+    assert "rank(s) failed" in (r.stderr + r.stdout)
+    assert time.time() - t0 < 90
+
+
 def test_cpu_chain_baseline_legs_agree():
     """bench.py's cpu_baseline "chain" legs (SURVEY 8d i-iii): the stage-after-stage run and the thread-per-block pipeline over
     64 k-item chunks are the same computation -- same number of access-code flags -- and every leg reports a rate"""

@@ -234,6 +234,51 @@ def test_chain_eight_captures_per_wave(gpu, po, wl, decim, ntaps, n_out, omega):
     assert np.array_equal(outs[8][0], outs[1][0]) and np.array_equal(outs[8][1], outs[1][1])
 
 
+@pytest.mark.parametrize("limit", [1, 7, 8, 9, 1003, 4096, 6999])
+def test_clock_recovery_stops_at_its_output_limit(gpu, po, wl, limit):
+    """`oo < noutput_items` (digital_clock_recovery_mm_ff.cc:113) with a limit that is not a multiple of the
+    eight symbols a pass of mm_rows_kernel takes: both forms of the loop stop at exactly `limit` symbols, with the
+    oracle's symbols (the eight-captures form used to run whole passes of eight past the limit)"""
+    import ctypes
+    torch = _torch()
+    c, c4 = wl.CFG2, wl.CFG4
+    S, n_out = 11, 70_000
+    n = n_out * 4
+    xs = [wl.fsk4_capture(n, stream_id=40 + s) for s in range(S)]
+    dev = torch.device("cuda", 0)
+    d_in = torch.zeros((S, n, 2), dtype=torch.float32, device=dev)
+    for s in range(S):
+        d_in[s] = torch.from_numpy(xs[s].view(np.float32).reshape(-1, 2))
+    d_bits = torch.zeros((S, n_out), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    ch = _make_chain(gpu, wl, S, n)
+    ch.set_mode(gpu.MODE_GENERIC)
+    ch.set_max_symbols(limit)
+    st = torch.cuda.Stream(device=dev)
+    got = {}
+    for cpw in (8, 1):
+        ch.set_captures_per_wave(cpw)
+        d_bits.zero_(); d_n.zero_()
+        torch.cuda.synchronize()
+        ch.run_device(d_in, n, n, d_bits, n_out, d_n, st)
+        st.synchronize()
+        nb = d_n.cpu().numpy()
+        assert (nb == limit).all(), (cpw, nb)
+        p_soft, s_soft = ch.intermediate(1)
+        softs = []
+        for s in range(S):
+            soft = np.empty(limit, np.float32)
+            gpu.lib().grhip_memcpy_d2h(soft.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_soft + 4 * s * s_soft), limit * 4)
+            softs.append(soft)
+        got[cpw] = (softs, d_bits.cpu().numpy()[:, :limit].copy())
+    dem_ref, _, _ = _oracle_chain(po, wl, xs[3])
+    ref, _ = po.chain_mm(c4["omega"], c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], dem_ref)
+    assert bits_equal(got[8][0][3], ref[:limit])
+    for s in range(S):
+        assert bits_equal(got[8][0][s], got[1][0][s]), s
+    assert np.array_equal(got[8][1], got[1][1])
+
+
 @pytest.mark.parametrize("S", [1600, 2100])
 def test_chain_big_batches_take_the_eight_captures_form_by_themselves(gpu, po, wl, S):
     """batches of 1600 captures and more: the library's own choice of the clock-recovery form (eight captures per wave, the
@@ -285,6 +330,66 @@ def test_chain_big_batches_take_the_eight_captures_form_by_themselves(gpu, po, w
     ch.run_device(d_in, n, n, d_bits, n_out, d_n, st)
     st.synchronize()
     assert np.array_equal(d_n.cpu().numpy(), nb) and np.array_equal(d_bits.cpu().numpy(), first)
+
+
+def test_chain_full_size_captures_in_a_big_batch(gpu, po, wl):
+    """the benchmarked shape at its size -- 1600 captures of 10 M samples (a few distinct ones, repeated
+    with different neighbours in their wavefronts) through the library's own choice of the clock-recovery form
+    (mm_rows_kernel<1024>, the loop and the FIR on CUs of their own, 32 time slices, ~4900 ring top-ups per capture).
+    The originals are checked stage by stage against the oracle: demodulator within the FAST tolerance, symbols exact on
+    that input, bit decisions exact on those symbols; every copy equals its original bit for bit."""
+    import ctypes
+    torch = _torch()
+    c, c4 = wl.CFG2, wl.CFG4
+    S, n = 1600, 10_000_000
+    n_out = n // 4
+    K = 3
+    free_b, _ = torch.cuda.mem_get_info(0)
+    if free_b < S * (n * 8 + n_out * 10) + (8 << 30):
+        pytest.skip("needs ~150 GB of device memory")
+    xs = [wl.fsk4_capture(n, stream_id=300 + k) for k in range(K)]
+    dev = torch.device("cuda", 0)
+    d_in = torch.empty((S, n, 2), dtype=torch.float32, device=dev)
+    src = [torch.from_numpy(x.view(np.float32).reshape(-1, 2)).to(dev) for x in xs]
+    order = [(s * 7 + s // 8) % K for s in range(S)]        # neighbours in a wave of eight differ from wave to wave
+    for s in range(S):
+        d_in[s] = src[order[s]]
+    del src
+    d_bits = torch.zeros((S, n_out), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    ch = _make_chain(gpu, wl, S, n)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    ch.run_device(d_in, n, n, d_bits, n_out, d_n, st)
+    st.synchronize()
+    nb = d_n.cpu().numpy()
+    p_dem, s_dem = ch.intermediate(0)
+    p_soft, s_soft = ch.intermediate(1)
+    first = {}
+    for s in range(S):
+        first.setdefault(order[s], s)
+    for k in range(K):
+        s0 = first[k]
+        dem = np.empty(n_out, np.float32)
+        gpu.lib().grhip_memcpy_d2h(dem.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_dem + 4 * s0 * s_dem), n_out * 4)
+        dem_ref = po.chain_xlating_demod(c["decim"], wl.cfg2_proto_taps(), c["center_freq"], c["fs"], c["demod_gain"], xs[k])
+        ok, worst = demod_close(dem, dem_ref)
+        assert ok, (k, worst)
+        ref, _ = po.chain_mm(c4["omega"], c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], dem)
+        assert nb[s0] == len(ref), k
+        soft = np.empty(nb[s0], np.float32)
+        gpu.lib().grhip_memcpy_d2h(soft.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_soft + 4 * s0 * s_soft), int(nb[s0]) * 4)
+        assert bits_equal(soft, ref), k
+        mine = po.CorrelateAccessCode(wl.access_code_string(), c4["threshold"]).work(po.binary_slicer_fb(soft))
+        b0 = d_bits[s0, :int(nb[s0])].cpu().numpy()
+        assert np.array_equal(b0, mine), k
+        want = len(range(100, len(ref) - 48, c4["sync_period_syms"]))
+        assert want - 1 <= int(np.count_nonzero(b0 & 2)) <= want + 1
+    # every copy like its original (compared on the device: 4 GB of decisions)
+    for k in range(K):
+        rows = torch.tensor([s for s in range(S) if order[s] == k], device=dev)
+        assert bool((d_n[rows] == int(nb[first[k]])).all())
+        assert bool((d_bits[rows] == d_bits[first[k]]).all()), k
 
 
 def test_chain_more_symbols_than_the_nominal_clock_gives(gpu, po, wl):

@@ -90,9 +90,66 @@ def test_fft_linearity_and_parseval_full_size(gpu):
 def test_fft_errors(gpu):
     with pytest.raises(gpu.GrhipError) as e:
         gpu.fft_vcc(0, True, [], False)
-    assert e.value.code == -2
+    assert e.value.code == -2                  # gri_fft.cc:104-105: "invalid fft_size"
     with pytest.raises(gpu.GrhipError):
-        gpu.fft_vcc(48, True, [], False)
+        gpu.fft_vcc((1 << 26) + 2, True, [], False)      # beyond what one handle's work buffers are sized for
+
+
+def _dft64(x, N, forward, w=None, shift=False):
+    """gr_fft_vcc_fftw::work (general/gr_fft_vcc_fftw.cc:64-100) with the transform in float64"""
+    v = x.reshape(-1, N).astype(np.complex128)
+    if w is not None:
+        v = v * w.astype(np.float64)
+    elif (not forward) and shift:
+        v = np.roll(v, -(N // 2), axis=1)                # dst[i] = in[(i + floor(N/2)) mod N]
+    X = np.fft.fft(v, axis=1) if forward else np.fft.ifft(v, axis=1) * N
+    if forward and shift:
+        X = np.roll(X, -((N + 1) // 2), axis=1)          # out[i] = X[(i + ceil(N/2)) mod N]
+    return X.reshape(-1)
+
+
+# every size class the reference's gri_fft_complex takes (any fft_size > 0, general/gri_fft.cc:97-123) and the
+# radix-16 kernels do not: small non-powers of two (direct DFT), other non-powers of two (Bluestein on 128 ... 32768
+# points), powers of two above 8192 (four-step), a non-power of two above 4096 (Bluestein on a four-step transform)
+@pytest.mark.parametrize("N,nvec", [(3, 50), (7, 33), (48, 21), (100, 13), (127, 5), (129, 7), (1000, 9), (1023, 3), (4097, 2),
+                                    (12000, 3), (16384, 5), (32768, 2), (65536, 3), (1 << 20, 1)])
+@pytest.mark.parametrize("forward", [True, False])
+def test_fft_any_size_vs_float64(gpu, N, nvec, forward):
+    rng = np.random.default_rng(N + 3 * int(forward))
+    x = _rc(rng, N * nvec)
+    ref = _dft64(x, N, forward)
+    got = gpu.fft_vcc(N, forward, [], False).work(nvec, x)
+    err = np.abs(got - ref).reshape(nvec, N).max(1) / np.abs(ref).reshape(nvec, N).max(1)
+    assert err.max() <= 1e-6 * max(np.log2(N), 1), (int(err.argmax()), float(err.max()))
+
+
+@pytest.mark.parametrize("N,nvec", [(48, 9), (100, 5), (1000, 4), (1001, 3), (16384, 2), (12000, 2)])
+@pytest.mark.parametrize("forward,shift,win", [(True, True, False), (False, True, False), (True, False, True),
+                                               (False, True, True), (True, True, True)])
+def test_fft_any_size_window_and_shift(gpu, N, nvec, forward, shift, win):
+    """window, ifft-shift (floor(N/2), backward and only without a window) and fft-shift (ceil(N/2), forward), odd N included"""
+    rng = np.random.default_rng(17 + N)
+    x = _rc(rng, N * nvec)
+    w = np.hamming(N).astype(np.float32) if win else None
+    ref = _dft64(x, N, forward, w, shift)
+    blk = gpu.fft_vcc(N, forward, w if win else [], shift)
+    got = blk.work(nvec, x)
+    assert rel_err_max(got, ref) <= 1e-6 * np.log2(N)
+    assert blk.set_window(np.ones(N - 1, np.float32)) is False
+    assert blk.set_window(np.ones(N, np.float32)) is True
+
+
+def test_fft_any_size_many_vectors_and_round_trip(gpu):
+    """more vectors than one work-buffer chunk holds (Bluestein: 2^25 / L per pass), and inverse(forward(x)) = N x"""
+    rng = np.random.default_rng(3)
+    N, nvec = 1000, 20000                                # L = 2048: chunks of 16384 vectors
+    x = _rc(rng, N * nvec)
+    X = gpu.fft_vcc(N, True, [], False).work(nvec, x)
+    ref = _dft64(x, N, True)
+    err = np.abs(X - ref).reshape(nvec, N).max(1) / np.abs(ref).reshape(nvec, N).max(1)
+    assert err.max() <= 1e-5
+    back = gpu.fft_vcc(N, False, [], False).work(nvec, X)
+    assert rel_err_max(back / N, x) < 5e-6
 
 
 def _pfb_streams(x, M, tpf):
@@ -234,5 +291,23 @@ def test_fft_filter_ccc_set_taps(gpu, po):
     got = blk.work(ns2, x[:ns2])                 # tail was cleared by set_taps
     ref = po.FftFilterCcc(1, t2).filter(ns2, x[:ns2])
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
-    with pytest.raises(gpu.GrhipError):
-        gpu.fft_filter_ccc(1, _rc(rng, 5000))    # would need a 16384-point FFT
+
+
+@pytest.mark.parametrize("ntaps,decim", [(5000, 1), (8192, 2), (8193, 4)])
+def test_fft_filter_ccc_beyond_4096_taps(gpu, po, ntaps, decim):
+    """filters whose transform is larger than the register kernels take (fftsize = 2 * 2^ceil(log2 ntaps) >= 16384,
+    gri_fft_filter_ccc_generic.cc:98-118 sizes it from ntaps without a cap): the four-step form of the same
+    overlap-add; sizes as the reference computes them, results against the direct-form FIR the block stands for
+    (the oracle's O(N^2) double transform is not run at these sizes), tail carried across calls"""
+    rng = np.random.default_rng(ntaps)
+    taps = (_rc(rng, ntaps) / np.sqrt(ntaps)).astype(np.complex64)
+    blk = gpu.fft_filter_ccc(decim, taps)
+    fftsize = int(2 * 2 ** np.ceil(np.log2(ntaps)))
+    ns = blk.nsamples()
+    assert ns == fftsize - ntaps + 1 and blk.decimation() == decim
+    nout = 3 * ns
+    x = _rc(rng, nout * decim)
+    got = np.concatenate([blk.work(ns, x[: ns * decim]), blk.work(2 * ns, x[ns * decim:])])
+    xin = np.concatenate([np.zeros(ntaps - 1, np.complex64), x])
+    direct = po.fir_ccc(taps, xin, nout, decim)
+    assert np.abs(got - direct).max() <= 1e-5 * max(np.abs(direct).max(), 1e-3 * np.abs(taps).sum())

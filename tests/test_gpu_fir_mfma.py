@@ -85,6 +85,57 @@ def test_block_floating_point_scaling(gpu, po, scale):
     assert rel_err_max(got, ref) <= TOL and _per_element(got, ref) <= TOL
 
 
+@pytest.mark.parametrize("where", [3001, 20000, 23999])
+def test_amplitude_step_inside_a_tile(gpu, po, where):
+    """a 60 dB step inside one staged tile (a TDMA slot edge).  The matrix-core engine scales a tile of ~8000
+    input samples by ONE power of two taken from its largest sample, so its error is about 2^-22 of the TILE's peak times
+    sum|h| -- absolute, not relative to the local signal: on the quiet side of the step it keeps the infinity-norm
+    tolerance and the bound written in include/grhip.h, not the per-element 1e-5 the f32 engines keep there."""
+    rng = np.random.default_rng(where)
+    ntaps, decim, n = 256, 4, 12000
+    nin = n * decim + ntaps - 1
+    x = _rand_c(rng, nin)
+    x[:where] *= np.float32(1e-3)                      # quiet, then loud
+    taps = (rng.uniform(-1, 1, ntaps) / 16).astype(np.float32)
+    ref = po.fir_ccf(taps, x, n, decim)
+    blk = gpu.fir_filter_ccf(decim, taps)
+    got = blk.work(n, x)
+    assert rel_err_max(got, ref) <= TOL
+    quiet = np.arange(n) < (where - ntaps) // decim - 1           # outputs whose whole window is quiet
+    assert quiet.sum() > 100
+    bound = 2.0 ** -21 * np.abs(taps).sum() * np.abs(x).max()     # grhip.h: FAST-mode error of this engine
+    assert np.abs(got[quiet] - ref[quiet]).max() <= bound
+    loud = np.arange(n) > where // decim + 1
+    assert _per_element(got[loud], ref[loud]) <= TOL
+    # the f32 vector engine keeps the local precision
+    blk.set_mode(gpu.MODE_FAST_VALU)
+    got_v = blk.work(n, x)
+    assert _per_element(got_v[quiet], ref[quiet]) <= TOL and _per_element(got_v[loud], ref[loud]) <= TOL
+
+
+@pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
+@pytest.mark.parametrize("pos", [5, 17000, 30011])
+def test_one_non_finite_sample_stays_local(gpu, po, bad, pos):
+    """one Inf / NaN sample.  The reference corrupts the outputs whose window holds it (ntaps / decim of
+    them); the block-floating-point scale must not take it for the tile's peak (that flushed or poisoned the whole
+    tile): everything further than one 16-output block from those outputs still meets the tolerance."""
+    rng = np.random.default_rng(pos)
+    ntaps, decim, n = 256, 4, 10000
+    nin = n * decim + ntaps - 1
+    x = _rand_c(rng, nin)
+    taps = (rng.uniform(-1, 1, ntaps) / 16).astype(np.float32)
+    clean = po.fir_ccf(taps, x, n, decim)
+    x[pos] = np.complex64(complex(bad, 1.0))
+    got = gpu.fir_filter_ccf(decim, taps).work(n, x)
+    idx = np.arange(n)
+    first, last = (pos - ntaps + 1 + decim - 1) // decim, pos // decim      # outputs whose window holds the sample
+    far = (idx < first - 32) | (idx > last + 32)
+    assert np.isfinite(got[far]).all()
+    assert np.abs(got[far] - clean[far]).max() <= TOL * np.abs(clean).max()
+    hit = (idx >= max(first, 0)) & (idx <= min(last, n - 1))
+    assert not np.isfinite(got[hit]).any()                                   # as in the reference
+
+
 def test_all_zero_and_impulse(gpu, po):
     ntaps, decim, n = 256, 4, 6000
     nin = n * decim + ntaps - 1

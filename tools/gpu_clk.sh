@@ -6,7 +6,7 @@ O=$R/gpurun_out/prof_clk
 rm -rf $O; mkdir -p $O
 for w in 2; do
   export GRHIP_WGPCU=$w
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $O/w$w -- python3 $R/bench.py --steps 6 --warmup 2 --captures 64 --ramp-ms 300 --no-cpu-baseline > $O/bench_w$w.log 2>&1
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $O/w$w -- python3 $R/bench.py --steps 6 --warmup 2 --captures 64 --ramp-ms 300 --no-cpu-baseline --chain-captures 0 > $O/bench_w$w.log 2>&1
 done
 cd $O
 python3 - <<'PY'

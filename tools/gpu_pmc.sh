@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
-BENCH="python3 $R/bench.py --steps 6 --warmup 2 --captures 8 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 6 --warmup 2 --captures 8 --no-cpu-baseline --chain-captures 0"
 rocprofv3 -L > $O/counters.txt 2>&1
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \

@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_pmc2
 mkdir -p $O
-BENCH="python3 $R/bench.py --steps 6 --warmup 2 --captures 8 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 6 --warmup 2 --captures 8 --no-cpu-baseline --chain-captures 0"
 i=0
 for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_STALL" "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES"; do
   i=$((i+1))

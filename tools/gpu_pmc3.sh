@@ -11,7 +11,7 @@ for set in "SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_VME
            "TCC_EA0_RDREQ_LEVEL TCC_EA0_RDREQ TCC_EA0_RDREQ_DRAM_CREDIT_STALL TCC_BUSY TCC_CYCLE TCC_HIT TCC_MISS" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $O/k$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_k$i.log 2>&1 || echo "set $i bench failed" >> $O/progress.log
+  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $O/k$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --chain-captures 0 > $O/bench_k$i.log 2>&1 || echo "set $i bench failed" >> $O/progress.log
   timeout -k 10 100 rocprofv3 --pmc $set --output-format csv -d $O/m$i -- $R/tools/dbg/readbw > $O/readbw_m$i.log 2>&1 || echo "set $i readbw failed" >> $O/progress.log
   echo "set $i done" >> $O/progress.log
 done

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 python3 $R/bench.py > $O/bench_line.json 2> $O/bench_stderr.log
-BENCH="python3 $R/bench.py --no-cpu-baseline"
+BENCH="python3 $R/bench.py --no-cpu-baseline --chain-captures 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH > $O/bench_trace.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $BENCH > $O/bench_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_write -- $BENCH > $O/bench_pmc_write.log 2>&1

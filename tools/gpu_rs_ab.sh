@@ -7,7 +7,7 @@ rc=$?; tail -5 gpurun_out/rs_tests.log
 [ $rc -ne 0 ] && exit $rc
 for rep in 1 2; do
 for v in ${VARIANTS:-0 1}; do
-  env GRHIP_LIB=$L/libgrhip_diag.so GRHIP_MF_RS=$v timeout -k 10 200 python bench.py --steps 20 --warmup 3 --captures ${CAPTURES:-64} --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('GRHIP_MF_RS=$v','kernel_ms',round(d['roofline']['kernel_ms'],5),'value',round(d['value']),'frac',round(d['roofline']['frac'],4), d['roofline'].get('kernel'))" >> gpurun_out/rs_ab.log || exit 1
+  env GRHIP_LIB=$L/libgrhip_diag.so GRHIP_MF_RS=$v timeout -k 10 200 python bench.py --steps 20 --warmup 3 --captures ${CAPTURES:-64} --no-cpu-baseline --chain-captures 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('GRHIP_MF_RS=$v','kernel_ms',round(d['roofline']['kernel_ms'],5),'value',round(d['value']),'frac',round(d['roofline']['frac'],4), d['roofline'].get('kernel'))" >> gpurun_out/rs_ab.log || exit 1
 done; done
 cat gpurun_out/rs_ab.log
 timeout -k 10 200 python -m pytest tests/test_gpu_fir.py -q -m gpu -k "parity_numbers" -s > gpurun_out/rs_parity.log 2>&1; grep -i "per element\|steady\|passed\|failed" gpurun_out/rs_parity.log | tail -5
