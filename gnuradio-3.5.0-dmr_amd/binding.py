@@ -980,6 +980,19 @@ class pfb_channelizer_ccf(_Block):
             _stream(stream)))
 
 
+def _pfb_hier_work_device(self, noutput_items, d_in, d_out, out_stride_items, stream=None):
+    """blks2.pfb_channelizer_ccf (hier block) in one call: one interleaved stream in (taps_per_filter * numchans history
+    items in front), numchans streams out (channel k at d_out + k * out_stride_items)"""
+    L = lib()
+    L.grhip_pfb_channelizer_ccf_hier_work_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                             C.c_void_p]
+    return _check(L.grhip_pfb_channelizer_ccf_hier_work_device(self._h, int(noutput_items), _devptr(d_in), _devptr(d_out),
+                                                               int(out_stride_items), _stream(stream)))
+
+
+pfb_channelizer_ccf.hier_work_device = _pfb_hier_work_device
+
+
 class pfb_decimator_ccf(_Block):
     """gr.pfb_decimator_ccf(decim, taps, channel)"""
     _destroy = "grhip_pfb_decimator_ccf_destroy"

@@ -1,6 +1,7 @@
 // capi_fft.hip -- C ABI for gr_fft_vcc and gr_pfb_channelizer_ccf.
 #include <cmath>
 
+#include "digital_kernels.h"
 #include "fft_kernels.h"
 #include "grhip_internal.h"
 
@@ -32,6 +33,7 @@ struct grhip_pfb_channelizer_ccf : HandleBase {
     std::vector<float> ftaps;      // [M][tpf] reversed
     std::vector<int> idxlut;
     DevBuf d_ftaps, d_idxlut, d_dft;
+    DevBuf d_hier_in, d_hier_vec;     // hier entry, shapes without a fused kernel: de-interleaved streams, output vectors
 
     // set_taps (filter/gr_pfb_channelizer_ccf.cc:104-139)
     int set_taps(const float *taps, size_t ntaps)
@@ -179,6 +181,7 @@ void grhip_pfb_channelizer_ccf_destroy(grhip_pfb_channelizer_ccf *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     h->d_ftaps.release(); h->d_idxlut.release(); h->d_dft.release();
+    h->d_hier_in.release(); h->d_hier_vec.release();
     h->destroy_base();
     delete h;
 }
@@ -235,6 +238,46 @@ int grhip_pfb_channelizer_ccf_general_work_device(grhip_pfb_channelizer_ccf *h, 
     a.out = (float2 *)d_out; a.nout = nvalid;
     rc = launch_pfb(a, h->pick(stream));
     return rc ? rc : noutput_items;
+}
+
+int grhip_pfb_channelizer_ccf_hier_work_device(grhip_pfb_channelizer_ccf *h, int noutput_items, const void *d_in,
+                                               void *d_out, size_t out_stride_items, void *stream)
+{
+    if (!h) return fail(GRHIP_EINVAL, "null handle");
+    if (noutput_items < 0) return fail(GRHIP_EINVAL, "negative noutput_items");
+    int rc = h->bind();
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(h->setter_mutex);
+        if (h->updated) { h->updated = false; return 0; }      // .cc:169-172
+    }
+    if (noutput_items == 0) return 0;
+    if ((size_t)noutput_items > out_stride_items) return fail(GRHIP_EINVAL, "out_stride_items smaller than noutput_items");
+    hipStream_t st = h->pick(stream);
+    int tc = 0;
+    const long long nvalid = pfb_valid_outputs(h, noutput_items, &tc);
+    PfbArgs a;
+    a.M = (int)h->M; a.tpf = (int)h->taps_per_filter; a.rate_ratio = h->rate_ratio;
+    a.ftaps = h->d_ftaps.as<float>(); a.idxlut = h->d_idxlut.as<int>(); a.dft = h->d_dft.as<float2>();
+    a.in = (const float2 *)d_in; a.stride = 0; a.out = nullptr; a.nout = nvalid;
+    a.out_streams = (float2 *)d_out; a.out_stride = (long long)out_stride_items;
+    rc = launch_pfb_hier(a, st);
+    if (rc != -1) return rc ? rc : noutput_items;
+    // no fused kernel for this shape: the three blocks one after the other (stream_to_streams, the channeliser,
+    // vector_to_streams = the data movement of stream_to_streams on the output vectors)
+    const size_t per = (size_t)h->taps_per_filter + (size_t)tc + 1;        // items per de-interleaved stream incl. history
+    if ((rc = h->d_hier_in.reserve(per * h->M * sizeof(float2)))) return rc;
+    if ((rc = h->d_hier_vec.reserve((size_t)(nvalid > 0 ? nvalid : 1) * h->M * sizeof(float2)))) return rc;
+    const long long items_in = (long long)h->taps_per_filter + tc;          // what the interleaved stream holds per channel
+    if ((rc = launch_streams(true, const_cast<void *>(d_in), h->d_hier_in.p, (long long)per, (int)h->M, sizeof(float2), items_in, st)))
+        return rc;
+    a.in = h->d_hier_in.as<float2>(); a.stride = (long long)per; a.out = h->d_hier_vec.as<float2>();
+    a.out_streams = nullptr; a.out_stride = 0;
+    if ((rc = launch_pfb(a, st))) return rc;
+    if (nvalid > 0 &&
+        (rc = launch_streams(true, h->d_hier_vec.p, d_out, (long long)out_stride_items, (int)h->M, sizeof(float2), nvalid, st)))
+        return rc;
+    return noutput_items;
 }
 
 int grhip_pfb_channelizer_ccf_general_work(grhip_pfb_channelizer_ccf *h, int noutput_items,

@@ -48,8 +48,14 @@ struct PfbArgs {
     long long stride;
     float2 *out;        // [nout][M]
     long long nout;
+    // launch_pfb_hier only: `in` is the single interleaved stream (stream j's item m = in[m M + j], tpf M history items in front)
+    float2 *out_streams = nullptr;      // channel k's stream at out_streams + k * out_stride
+    long long out_stride = 0;
 };
 int launch_pfb(const PfbArgs &a, hipStream_t st);
+// blks2's hier block in one pass (stream_to_streams -> pfb -> vector_to_streams); GRHIP_OK, < 0 on error, or -1 when
+// the shape has no fused kernel (the caller then runs the three blocks)
+int launch_pfb_hier(const PfbArgs &a, hipStream_t st);
 
 // gr_fft_filter_ccc, fused overlap-save on 4096-point blocks (ntaps <= 2049)
 constexpr int OLS_N = 4096, OLS_MAX_TAPS = 2049;

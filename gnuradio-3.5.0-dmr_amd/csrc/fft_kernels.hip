@@ -475,7 +475,12 @@ typedef const float __attribute__((address_space(4))) *pfb_cfloat_p;
 // Persistent workgroups walk the tiles.  NT = padded taps per filter / 8: for NT in 1..4 the wave's taps are read once
 // per launch and stay in SGPRs, the FIR is straight-line code and the tile's 512 + 8 NT samples per stream are nine
 // 64-lane rounds of range-checked buffer loads (no branches); NT = 0 takes any length with the taps read in the loop.
-template <int M, int NT>
+// IL (round 3): the hier block's form (blks2impl/pfb_channelizer.py:25-75: stream_to_streams -> pfb -> vector_to_streams) in
+// ONE pass -- the input is the single interleaved stream (stream j's item m is x[m M + j]; the tile's samples are one
+// contiguous stretch, fetched by the whole workgroup with 16-byte loads and dealt to the streams' LDS rows), the output
+// is M streams (a.out_streams + k a.out_stride; a lane's bin k goes to stream k, 64 consecutive items per wave and store).
+// 16 B of HBM traffic per sample instead of the 48 of the three blocks one after the other; same arithmetic, same results.
+template <int M, int NT, bool IL = false>
 __global__ void __launch_bounds__(64 * M) __attribute__((amdgpu_waves_per_eu(M == 8 && NT > 0 ? 6 : 1)))       // (M = 8, resident taps: 40 KB of LDS -> three per CU)
 pfb_os1_kernel(const PfbArgs a, long long ntiles)
 {
@@ -503,8 +508,10 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
         for (int i = 0; i < R * NT; ++i) hres[i] = i < a.tpf ? taps[i] : 0.f;
     }
     // stream j: tpf history items + nout new ones; past that the range check returns zeros (and moves no bytes)
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.in + (long long)j * a.stride), 0,
-                                                                        (int)((a.nout + a.tpf) * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = IL
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.in), 0, (int)((a.nout + a.tpf) * 8 * M), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.in + (long long)j * a.stride), 0,
+                                            (int)((a.nout + a.tpf) * 8), 0x00020000);
     constexpr int OOB = (int)0xfffffff0;
     const int tot = TT + tpfp;
     pfb_f32x2 *dst = xs + (size_t)j * XS;
@@ -516,8 +523,22 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
     // behind the sample area, read at a wave-uniform address: in order with the sample reads, where scalar loads in the
     // loop shared a counter that can only be waited to zero)
     constexpr int NR = NT ? (TT + R * NT + 63) / 64 : 12;
-    pfb_f32x2 pv[NR];
+    pfb_f32x2 pv[IL ? 1 : NR];
+    // IL: the tile's (TT + tpfp) M interleaved samples, two per lane and round of the whole workgroup
+    constexpr int NRI = IL ? ((NT ? TT + R * NT : TT + 256) * M + 128 * M - 1) / (128 * M) : 1;
+    pfb_f32x4 pvi[NRI];
     auto request = [&](long long tile_) __attribute__((always_inline)) {
+        if (IL) {
+            const long long b0 = (tile_ * TT + 1) * (8ll * M) + 16 * t;       // (< 2^32: the launcher checks the stream's size)
+#pragma unroll
+            for (int i = 0; i < NRI; ++i) {
+                const int sidx = 2 * (t + 64 * M * i);
+                if (NT || sidx < tot * M)
+                    pvi[i] = __builtin_bit_cast(pfb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                 xr, sidx < tot * M ? (int)(unsigned)(b0 + 16ll * 64 * M * i) : OOB, 0, 0));
+            }
+            return;
+        }
         const int vb = (int)((tile_ * TT + 1) * 8) + 8 * ln;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -536,6 +557,22 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long t0 = tile * TT;
         // ---- stage stream j: items in_j[t0+1 .. t0+TT+tpfp]
+        if (IL) {
+            // interleaved sample s of the tile is item s / M of stream s mod M: every lane deals its two samples to their rows
+#pragma unroll
+            for (int i = 0; i < NRI; ++i) {
+                const int sidx = 2 * (t + 64 * M * i);
+                if (!NT && sidx >= tot * M) break;
+                if (sidx < tot * M) {
+                    const int m0 = sidx / M, j0 = sidx - m0 * M;
+                    xs[(size_t)j0 * XS + m0 + (m0 >> 3)] = pfb_f32x2{pvi[i][0], pvi[i][1]};
+                    const int m1 = (sidx + 1) / M, j1 = sidx + 1 - m1 * M;
+                    xs[(size_t)j1 * XS + m1 + (m1 >> 3)] = pfb_f32x2{pvi[i][2], pvi[i][3]};
+                }
+            }
+            if (tile + gridDim.x < ntiles) request(tile + gridDim.x);
+            __syncthreads();
+        } else {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             if (!NT && 64 * i >= tot) break;
@@ -548,6 +585,7 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 
         // ---- FIR, 8 output vectors per lane: an 8-deep register window slides over the samples,
         // (re, im) pairs as 2-vectors: one v_pk_fma_f32 per tap and output
@@ -599,7 +637,7 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
         // lane's vector is 64 contiguous bytes, so storing it directly would touch 64 separate 64-byte segments per
         // instruction; the wave's 64 vectors go through its own (by then free) row of LDS instead and leave as
         // 1 KB-contiguous 16-byte stores.
-        constexpr bool COAL = M == 8;
+        constexpr bool COAL = M == 8 && !IL;
         constexpr int PIECES = M / 2 > 0 ? M / 2 : 1;         // 16-byte pieces per vector
         for (int tl = t; tl < TT; tl += 64 * M) {
             const long long tt = t0 + tl;
@@ -676,6 +714,11 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
                 }
                 continue;
             }
+            if (IL) {
+#pragma unroll
+                for (int k = 0; k < M; ++k) a.out_streams[(long long)k * a.out_stride + tt] = v[k];
+                continue;
+            }
             float2 *o = a.out + tt * M;
             if (M % 2 == 0) {
                 float4 *o4 = reinterpret_cast<float4 *>(o);
@@ -686,27 +729,60 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
                 for (int k = 0; k < M; ++k) o[k] = v[k];          // (an odd vector is not a whole number of 16-byte pieces)
             }
         }
-        if (M != 8) __syncthreads();                   // sl (= xs) belongs to the next tile's samples from here
+        if (M != 8 || IL) __syncthreads();             // sl (= xs) belongs to the next tile's samples from here
     }
 }
 
-template <int M, int NT>
+template <int M, int NT, bool IL = false>
 static int launch_pfb_os1_nt(const PfbArgs &a, size_t lds, hipStream_t st)
 {
     const int TT = 512;
     static size_t cfg = 0;
     if (lds > 48 * 1024 && lds > cfg) {
-        GRHIP_HIP(hipFuncSetAttribute((const void *)pfb_os1_kernel<M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GRHIP_HIP(hipFuncSetAttribute((const void *)pfb_os1_kernel<M, NT, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         cfg = lds;
     }
     const long long ntiles = (a.nout + TT - 1) / TT;
     int per_cu = 0;                                    // resident workgroups per CU (registers and LDS both count)
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfb_os1_kernel<M, NT>, 64 * M, lds) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfb_os1_kernel<M, NT, IL>, 64 * M, lds) != hipSuccess || per_cu < 1)
         per_cu = 1;
     const long long cap = (long long)per_cu * fft_num_cus();
-    hipLaunchKernelGGL((pfb_os1_kernel<M, NT>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(64 * M), lds, st, a, ntiles);
+    hipLaunchKernelGGL((pfb_os1_kernel<M, NT, IL>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(64 * M), lds, st, a, ntiles);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
+}
+
+// the hier block's fused form (interleaved stream in, M streams out): oversample rate 1, M = 2 / 4 / 8 / 16, up to 32 taps
+// per filter resident in SGPRs or any length from LDS; -1 = not this shape (the caller runs the three blocks one after the other)
+template <int M>
+static int launch_pfb_os1_il(const PfbArgs &a, hipStream_t st)
+{
+    const int R = 8, TT = 512;
+    const int tpfp = (a.tpf + R - 1) / R * R;
+    const int XS = (TT + tpfp + R) + (TT + tpfp + R) / R + 1;
+    const size_t lds = (size_t)M * XS * sizeof(float2) + (tpfp / R > 4 ? (size_t)M * tpfp * sizeof(float) : 0);
+    if (lds > 150 * 1024 || tpfp > 256) return -1;
+    if ((a.nout + a.tpf) * 8 * M > 0x7fffffffLL) return -1;        // the interleaved stream's buffer descriptor counts bytes in 32 bits
+    switch (tpfp / R) {
+    case 1: return launch_pfb_os1_nt<M, 1, true>(a, lds, st);
+    case 2: return launch_pfb_os1_nt<M, 2, true>(a, lds, st);
+    case 3: return launch_pfb_os1_nt<M, 3, true>(a, lds, st);
+    case 4: return launch_pfb_os1_nt<M, 4, true>(a, lds, st);
+    default: return launch_pfb_os1_nt<M, 0, true>(a, lds, st);
+    }
+}
+
+int launch_pfb_hier(const PfbArgs &a, hipStream_t st)
+{
+    if (a.nout <= 0) return GRHIP_OK;
+    if (a.rate_ratio != a.M || (((uintptr_t)a.in) & 15) || (((uintptr_t)a.out_streams) & 7)) return -1;
+    switch (a.M) {
+    case 2: return launch_pfb_os1_il<2>(a, st);
+    case 4: return launch_pfb_os1_il<4>(a, st);
+    case 8: return launch_pfb_os1_il<8>(a, st);
+    case 16: return launch_pfb_os1_il<16>(a, st);
+    }
+    return -1;
 }
 
 template <int M>

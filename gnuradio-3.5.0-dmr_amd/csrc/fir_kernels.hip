@@ -124,6 +124,156 @@ fir_generic_kernel(const float *__restrict__ taps_rev, int ntaps, const float *_
     }
 }
 
+// ---------------------------------------------------------------------------
+// (A') the same arithmetic as a tiled kernel (round 3): GRHIP_MODE_GENERIC is the only mode whose bit decisions are
+// the reference's, so it gets a throughput.  gr_fir_ccf_generic / gr_fir_ccc_generic (filter/gr_fir_XXX_generic.cc.t:59-79):
+// two complex accumulators, even taps into the first, odd taps into the second, every product and every sum a single
+// IEEE operation, the two added at the end -- kept term by term; what changes is where the operands come from.
+//   * a 256-lane workgroup takes a tile of 1024 outputs (four per lane, 256 apart: neighbouring lanes are neighbouring
+//     outputs); the tile's (1023 D + ntaps) samples are staged ONCE in LDS, de-interleaved into the D polyphase rows
+//     (sample u -> row u mod D, slot u / D), so that the lanes' reads of x[n D + i] are consecutive 8-byte slots
+//     (conflict-free) whatever the decimation; fir_generic_kernel's lanes read global memory at a stride of 8 D bytes,
+//     once per tap and output (L1-bound: 31 Gsamples/s);
+//   * per pair of taps: one 16-byte broadcast read of the two taps, eight sample reads, and the reference's operations as
+//     packed instructions on (re, im): v_pk_mul_f32 x 2, v_pk_add_f32 x 2 per complex-tap term (v_pk_mul + v_pk_add with
+//     real taps) -- unfused, so 256 complex taps at D = 4 cost 256 packed instructions per input sample: the ceiling is
+//     the vector pipes' non-FMA rate, about 130 Gsamples/s of input.
+// Bit-exactness is what tests/test_gpu_fir.py's generic-order cases check, on every shape they hold.
+// ---------------------------------------------------------------------------
+constexpr int GT_R = 4, GT_T = 256, GT_NT = GT_R * GT_T;
+
+template <int KIND>
+__global__ void __launch_bounds__(GT_T)
+fir_generic_tiled_kernel(const float *__restrict__ taps_rev, int ntaps, const float2 *__restrict__ in, long long n_in,
+                         float2 *__restrict__ out, long long n_out, int decim, const float2 *__restrict__ gtab)
+{
+    static_assert(KIND == FIR_CCF || KIND == FIR_CCC, "complex data");
+    typedef float gf2 __attribute__((ext_vector_type(2)));
+    typedef float gf4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int gu4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    const int D = decim, t = threadIdx.x;
+    const int per_row = GT_NT + (ntaps + D - 1) / D + 2;            // slots per polyphase row
+    gf2 *xs = reinterpret_cast<gf2 *>(gsm);                           // [D][per_row]
+    float *tp = reinterpret_cast<float *>(gsm + (((size_t)D * per_row * 8 + 15) & ~(size_t)15));   // taps (16-byte aligned: read in pairs)
+    const int tw = KIND == FIR_CCC ? 2 : 1;
+    const int ntp = ntaps & ~1;                                       // the pairs; an odd last tap goes to the first accumulator
+    for (int i = t; i < ntaps * tw; i += GT_T) tp[i] = taps_rev[i];
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in), 0,
+                                                                        (int)(n_in * 8 > 0x7ffffff0ll ? 0x7ffffff0ll : n_in * 8), 0x00020000);
+    const long long ntiles = (n_out + GT_NT - 1) / GT_NT;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long n0 = tile * GT_NT;
+        const long long u0 = n0 * D;                                  // first sample of the tile
+        const int span = (GT_NT - 1) * D + ntaps;                     // samples the tile touches
+        __syncthreads();                                              // the previous tile's reads are done (and the taps are in)
+        // ---- stage: 16-byte loads (two samples per lane), out-of-range lanes read zeros
+        for (int m = 2 * t; m < span; m += 2 * GT_T) {
+            const long long u = u0 + m;
+            const gu4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, u * 8 < 0x7ffffff0ll ? (int)(u * 8) : 0x7ffffff0, 0, 0);
+            const gf4 f = __builtin_bit_cast(gf4, v);
+            const int r0 = m % D, c0 = m / D;
+            xs[(size_t)r0 * per_row + c0] = gf2{f[0], f[1]};
+            const int m1 = m + 1, r1 = m1 % D, c1 = m1 / D;
+            if (m1 < span) xs[(size_t)r1 * per_row + c1] = gf2{f[2], f[3]};
+        }
+        __syncthreads();
+        gf2 a0[GT_R], a1[GT_R];
+#pragma unroll
+        for (int r = 0; r < GT_R; ++r) { a0[r] = gf2{0.f, 0.f}; a1[r] = gf2{0.f, 0.f}; }
+        int ph = 0, co = 0;                                           // i mod D, i / D
+        for (int i = 0; i < ntp; i += 2) {
+            const gf2 *x0 = xs + (size_t)ph * per_row + co + t;
+            int ph1 = ph + 1, co1 = co;
+            if (ph1 == D) { ph1 = 0; ++co1; }
+            const gf2 *x1 = xs + (size_t)ph1 * per_row + co1 + t;
+            if (KIND == FIR_CCC) {
+                const gf4 tt = *reinterpret_cast<const gf4 *>(tp + 2 * i);     // taps i, i + 1 (wave-uniform address)
+                const gf2 t0{tt[0], tt[1]}, t1{tt[2], tt[3]};
+#pragma unroll
+                for (int r = 0; r < GT_R; ++r) {
+                    const gf2 v0 = x0[r * GT_T], v1 = x1[r * GT_T];
+                    gf2 m1, m2;
+                    // d_taps[i] * input[i] as __mulsc3 does it for finite operands: (tr xr - ti xi, tr xi + ti xr)
+                    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(m1) : "v"(t0), "v"(v0));
+                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(m2) : "v"(t0), "v"(v0));
+                    a0[r] = a0[r] + (m1 + m2);
+                    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(m1) : "v"(t1), "v"(v1));
+                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(m2) : "v"(t1), "v"(v1));
+                    a1[r] = a1[r] + (m1 + m2);
+                }
+            } else {
+                const gf2 tt = *reinterpret_cast<const gf2 *>(tp + i);
+#pragma unroll
+                for (int r = 0; r < GT_R; ++r) {
+                    const gf2 v0 = x0[r * GT_T], v1 = x1[r * GT_T];
+                    a0[r] = a0[r] + v0 * gf2{tt[0], tt[0]};
+                    a1[r] = a1[r] + v1 * gf2{tt[1], tt[1]};
+                }
+            }
+            ph = ph1 + 1; co = co1;
+            if (ph == D) { ph = 0; ++co; }
+        }
+        if (ntaps & 1) {                                              // .cc.t:72-73: for (; i < ntaps; i++) acc0 += ...
+            const gf2 *x0 = xs + (size_t)ph * per_row + co + t;
+#pragma unroll
+            for (int r = 0; r < GT_R; ++r) {
+                const gf2 v0 = x0[r * GT_T];
+                if (KIND == FIR_CCC) {
+                    const gf2 t0{tp[2 * ntp], tp[2 * ntp + 1]};
+                    gf2 m1, m2;
+                    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(m1) : "v"(t0), "v"(v0));
+                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(m2) : "v"(t0), "v"(v0));
+                    a0[r] = a0[r] + (m1 + m2);
+                } else {
+                    a0[r] = a0[r] + v0 * gf2{tp[ntp], tp[ntp]};
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < GT_R; ++r) {
+            const long long n = n0 + r * GT_T + t;
+            if (n < n_out) {
+                const gf2 y = a0[r] + a1[r];
+                float2 o = make_float2(y[0], y[1]);
+                if (gtab) o = cmul_ref(o, gtab[n]);                   // gr_rotator::rotate: z = in * d_phase
+                out[n] = o;
+            }
+        }
+    }
+}
+
+static int g_gt_cus = 0;
+template <int KIND>
+static int launch_generic_tiled(const float *taps_rev, int ntaps, const void *in, void *out, long long n_out, int decim,
+                                const float2 *gtab, hipStream_t st)
+{
+    const int per_row = GT_NT + (ntaps + decim - 1) / decim + 2;
+    const size_t lds = (((size_t)decim * per_row * 8 + 15) & ~(size_t)15) + (size_t)(ntaps + 1) * (KIND == FIR_CCC ? 8 : 4);
+    static size_t cfg = 0;
+    if (lds > 64 * 1024 && lds > cfg) {
+        GRHIP_HIP(hipFuncSetAttribute((const void *)fir_generic_tiled_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cfg = lds;
+    }
+    if (g_gt_cus == 0) {
+        int dev = 0, n = 0;
+        GRHIP_HIP(hipGetDevice(&dev));
+        GRHIP_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        g_gt_cus = n > 0 ? n : 256;
+    }
+    const long long ntiles = (n_out + GT_NT - 1) / GT_NT;
+    long long per_cu = (long long)(160 * 1024) / (long long)(lds + 512);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    long long grid = per_cu * g_gt_cus;
+    if (grid > ntiles) grid = ntiles;
+    const long long n_in = (n_out - 1) * decim + ntaps;               // what the caller guarantees readable
+    hipLaunchKernelGGL(fir_generic_tiled_kernel<KIND>, dim3((unsigned)grid), dim3(GT_T), lds, st, taps_rev, ntaps,
+                       (const float2 *)in, n_in, (float2 *)out, n_out, decim, gtab);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
 template <int KIND, bool SEQ>
 static int launch_generic_inst(const float *taps_rev, int ntaps, const void *in, void *out, long long n_out, int decim,
                                size_t sh, hipStream_t st)
@@ -150,6 +300,15 @@ int launch_fir_generic(FirKind kind, const float *taps_rev, int ntaps, const voi
         case FIR_CCF: return launch_generic_inst<FIR_CCF, true>(taps_rev, ntaps, in, out, n_out, decim, sh, st);
         default: return launch_generic_inst<FIR_CCC, true>(taps_rev, ntaps, in, out, n_out, decim, sh, st);
         }
+    }
+    // the tiled form of the same arithmetic wherever it applies: complex data, a tile's worth of outputs, a decimation
+    // and a tap count whose tile fits LDS (16-byte loads: the stream on an 8-byte boundary is served by the range check
+    // only if it starts on a 16-byte one)
+    if (kind != FIR_FFF && ntaps >= 8 && n_out >= 2 * GT_NT && decim >= 1 && decim <= 16 &&
+        (size_t)decim * (GT_NT + ntaps / decim + 3) * 8 + (size_t)ntaps * 8 + 64 <= 150 * 1024 && (((uintptr_t)in) & 15) == 0 &&
+        ((n_out - 1) * decim + ntaps) * 8 < 0x7ffffff0ll) {
+        return kind == FIR_CCC ? launch_generic_tiled<FIR_CCC>(taps_rev, ntaps, in, out, n_out, decim, gtab, st)
+                               : launch_generic_tiled<FIR_CCF>(taps_rev, ntaps, in, out, n_out, decim, gtab, st);
     }
     dim3 grid((unsigned)((n_out + 255) / 256)), block(256);
     switch (kind) {

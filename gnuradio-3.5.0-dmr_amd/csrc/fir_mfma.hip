@@ -706,37 +706,59 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         const int sc_wr = sl * SCR_SEG + 8 * g + part;                  // + 2 i
 
         MF_STAMP_DECL;
+        constexpr int NCH = G::NCH;                   // operand chunks of a segment; chunk c is k-step c - CB b of block b
+        constexpr int PDK = (D == 2 && KS > 6) ? 1 : rs::PD;     // (decimation 2, long band: every block is live at once, one chunk ahead fits the registers)
         for (int p = 0; p < P; ++p) {
             const bool act = p >= 2 && p - 2 < n_my;
             unsigned char *buf = smem + (p & 1) * R::BUF;
-            f32x4 accf[NBLK];
-            // two blocks per half period; the operand chunks of a half are read PD ahead of their use
+            // CHUNK-major: every chunk is read once (32 instead of 80 16-byte reads per tile) and multiplied into every
+            // block whose band covers it, PDK chunks ahead of its use.  The order is pinned with sched_barriers:
+            // left alone, hipcc 7.2 merges the block-major form's repeated reads by itself but issues each read right
+            // in front of its first MFMA, an LDS round trip per chunk (1.2 us of matrix phase per half period instead of 0.5).
+            f32x4 m0[NBLK], m1[NBLK], lo[NBLK];
+            h16x8 Bh[PDK + 1], Bl[PDK + 1];
+            auto ld = [&](int c) __attribute__((always_inline)) {
+                const unsigned char *src = buf + rd_lane + chunk_off(c);
+                Bh[c % (PDK + 1)] = *reinterpret_cast<const h16x8 *>(src);
+                Bl[c % (PDK + 1)] = *reinterpret_cast<const h16x8 *>(src + PL);
+            };
             auto half = [&](int h) __attribute__((always_inline)) {
-                constexpr int NS = (NBLK / 2) * KS;
-                h16x8 Bh[rs::PD + 1], Bl[rs::PD + 1];
-                auto ld = [&](int idx) __attribute__((always_inline)) {
-                    const int b = (NBLK / 2) * h + idx / KS, j = idx % KS;
-                    const unsigned char *src = buf + rd_lane + chunk_off(CB * b + j);
-                    Bh[idx % (rs::PD + 1)] = *reinterpret_cast<const h16x8 *>(src);
-                    Bl[idx % (rs::PD + 1)] = *reinterpret_cast<const h16x8 *>(src + PL);
-                };
+                constexpr int HC = NCH / 2;
+                if (h == 0) {
 #pragma unroll
-                for (int k = 0; k < rs::PD; ++k) ld(k);
-                f32x4 m0, m1, lo;
-#pragma unroll
-                for (int idx = 0; idx < NS; ++idx) {
-                    if (idx + rs::PD < NS) ld(idx + rs::PD);
-                    const int j = idx % KS, sl_ = idx % (rs::PD + 1);
-                    if (j == 0) {
-                        m0 = f32x4{0.f, 0.f, 0.f, 0.f};
-                        m1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                        lo = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int b = 0; b < NBLK; ++b) {
+                        m0[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        m1[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        lo[b] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    if (j & 1) m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh[sl_], m1, 0, 0, 0);
-                    else m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh[sl_], m0, 0, 0, 0);
-                    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bl[sl_], lo, 0, 0, 0);
-                    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[j], Bh[sl_], lo, 0, 0, 0);
-                    if (j == KS - 1) accf[(NBLK / 2) * h + idx / KS] = (m0 + m1) + lo;
+#pragma unroll
+                    for (int c = 0; c < PDK; ++c) ld(c);
+                }
+#pragma unroll
+                for (int c = h * HC; c < (h ? NCH : HC); ++c) {
+                    if (c + PDK < NCH) ld(c + PDK);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int sl_ = c % (PDK + 1);
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) {
+                        const int j = c - CB * b;
+                        if (j < 0 || j >= KS) continue;
+                        if (j & 1) m1[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh[sl_], m1[b], 0, 0, 0);
+                        else m0[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh[sl_], m0[b], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) {
+                        const int j = c - CB * b;
+                        if (j < 0 || j >= KS) continue;
+                        lo[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bl[sl_], lo[b], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) {
+                        const int j = c - CB * b;
+                        if (j < 0 || j >= KS) continue;
+                        lo[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[j], Bh[sl_], lo[b], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             };
             MF_STAMP(7);
@@ -750,9 +772,10 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
                 // (nobody else reads it: Geo::HALO), read by the stagers after the next barrier
 #pragma unroll
                 for (int b = 0; b < NBLK; ++b) {
+                    const f32x4 accf = (m0[b] + m1[b]) + lo[b];
                     float *sb = reinterpret_cast<float *>(buf + scw_off + b * PL);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sb[sc_wr + 2 * i] = accf[b][i];
+                    for (int i = 0; i < 4; ++i) sb[sc_wr + 2 * i] = accf[i];
                 }
             }
             MF_STAMP(4);
@@ -771,17 +794,17 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
 #endif
     // pre-mix phasors of the lane's two samples of every staging round, e^{jw(2 ts + ROUND i - off)} and the next one:
     // tile independent, registers for the whole launch (the tile's scale goes into the binary16 conversion instead)
-    f32x2 W0[NI], W1[NI];
+    // (the second sample's phasor is one more product with e^{jw}: eighteen registers fewer than keeping both)
+    f32x2 W0[NI];
+    const f32x2 wstep{a.wstep.x, a.wstep.y};
     const cfloat_cp stab = (cfloat_cp)a.stab;
     if (PREMIX) {
         const float2 v = a.wlane[ts];
         const f32x2 wl{v.x, v.y};
-        const f32x2 wl1 = cmul_pk(wl, f32x2{a.wstep.x, a.wstep.y});
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const f32x2 S{stab[4 * i], stab[4 * i + 1]};          // e^{jw ROUND i}: every other entry of the 512-sample table
             W0[i] = cmul_pk(wl, S);
-            W1[i] = cmul_pk(wl1, S);
         }
     }
     if (DEMOD) {
@@ -862,8 +885,8 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         }
         if (lane == 0) wmax[w] = m;
     };
-    // ---- S: registers -> (pre-mix, scale, split) -> the planes of buffer q & 1 ----
-    auto stage = [&](int q, f32x4 (&pf)[NI], int &kslot) __attribute__((always_inline)) {
+    // ---- C: registers -> (pre-mix, scale, split) -> registers: the four binary16 pairs of every round (vector work) ----
+    auto convert = [&](int q, f32x4 (&pf)[NI], u32x4 (&cv)[NI], int &kslot) __attribute__((always_inline)) {
         float mt = wmax[0];
 #pragma unroll
         for (int i = 1; i < rs::NSTG; ++i) mt = __builtin_fmaxf(mt, wmax[i]);
@@ -872,24 +895,34 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         kslot = k;
         const float scale = __builtin_amdgcn_ldexpf(1.0f, k);
         const bool lz = lead_item_here(q);
-        unsigned char *dst = smem + (q & 1) * R::BUF + st_off;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             f32x2 e0{pf[i][0], pf[i][1]}, e1{pf[i][2], pf[i][3]};
             if (i == 0 && lz) e0 = f32x2{0.f, 0.f};
             if (PREMIX) {
                 e0 = cmul_pk(e0, W0[i]);
-                e1 = cmul_pk(e1, W1[i]);
+                e1 = cmul_pk(e1, cmul_pk(W0[i], wstep));
             }
             h16x2 rh, rlo, ih, ilo;
             split_scaled(e0.x, e1.x, scale, rh, rlo);
             split_scaled(e0.y, e1.y, scale, ih, ilo);
+            cv[i] = u32x4{__builtin_bit_cast(unsigned, rh), __builtin_bit_cast(unsigned, rlo), __builtin_bit_cast(unsigned, ih),
+                          __builtin_bit_cast(unsigned, ilo)};
+        }
+    };
+    // ---- S: the converted rounds into the four planes of buffer q & 1 (LDS store path only: two stores per round,
+    //      each to two planes a multiple of 256 bytes apart) ----
+    static_assert(PL % 256 == 0 && 3 * (PL / 256) < 256, "plane distance as a ds_write2st64_b32 offset");
+    auto store_planes = [&](int q, const u32x4 (&cv)[NI]) __attribute__((always_inline)) {
+        const int base = (q & 1) * R::BUF + st_off;                 // LDS byte address (dynamic LDS starts at 0)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
             if ((i + 1) * rs::ROUND <= SP || 2 * ts + i * rs::ROUND < SP) {
-                unsigned char *d = dst + i * ST_STEP;
-                *reinterpret_cast<h16x2 *>(d) = rh;
-                *reinterpret_cast<h16x2 *>(d + PL) = rlo;
-                *reinterpret_cast<h16x2 *>(d + 2 * PL) = ih;
-                *reinterpret_cast<h16x2 *>(d + 3 * PL) = ilo;
+                const int ad = base + i * ST_STEP;
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:0 offset1:%5\n\t"
+                             "ds_write2st64_b32 %0, %3, %4 offset0:%6 offset1:%7"
+                             :: "v"(ad), "v"(cv[i][0]), "v"(cv[i][1]), "v"(cv[i][2]), "v"(cv[i][3]),
+                                "n"(PL / 256), "n"(2 * (PL / 256)), "n"(3 * (PL / 256)) : "memory");
             }
         }
     };
@@ -993,11 +1026,18 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
     };
 
     // one period: pfL takes the loads of tile p, pfS holds tile p - 1 (complete: every period ends with the wave's
-    // vector-memory counter at zero); kslot: the exponent of tile p - 3 on entry (the epilogue's), of tile p - 1 on exit.
-    // The loads fly for the whole period -- behind the epilogue, the maximum and the staging of the other register
-    // set -- and are waited for ONCE, at its end, with a wait the compiler's counter bookkeeping understands
-    // (__builtin_amdgcn_s_waitcnt): a set that is loaded in one trip of the loop and used in the next makes hipcc 7.2
-    // wait for "all but the 8 youngest" operations at the first use, i.e. for the loads just issued.
+    // vector-memory counter at zero, and its maxima were published before the last barrier); kslot: the exponent of
+    // tile p - 3 on entry (the epilogue's), of tile p - 1 on exit.
+    //   first half   (vector work)   loads of tile p out; epilogue of tile p - 3; tile p - 1 converted in registers
+    //   -- barrier: the epilogue has left buffer (p-1)&1 --
+    //   second half  (LDS stores)    tile p - 1 into the planes; wait for tile p; its maxima
+    //   -- barrier --
+    // The two halves are bound by different units -- vector issue and the LDS store path (a stager's 36 four-byte
+    // stores per tile took as long as its 120 conversion instructions) -- so each gets a half to itself and the matrix
+    // waves' MFMAs run beside both.  The loads fly for the whole period and are waited for ONCE, with a wait the
+    // compiler's counter bookkeeping understands (__builtin_amdgcn_s_waitcnt): a set that is loaded in one trip of the
+    // loop and used in the next makes hipcc 7.2 wait for "all but the 8 youngest" operations at the first use, i.e.
+    // for the loads just issued.
     constexpr int LA = (NI + 1) / 2;            // rounds requested at the period's start, the rest behind the epilogue
     auto period = [&](int p, f32x4 (&pfL)[NI], f32x4 (&pfS)[NI], int &kslot) __attribute__((always_inline)) {
         MF_STAMP(7);
@@ -1010,13 +1050,15 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         issue_loads(p, pfL, LA, NI);
         MF_STAMP(1);
         const bool sact = p >= 1 && p - 1 < n_my;
-        if (sact) tile_max(p - 1, pfS);
+        u32x4 cv[NI];
+        if (sact) convert(p - 1, pfS, cv, kslot);
         MF_STAMP(2);
         rs_barrier();
         MF_STAMP(3);
-        if (sact) stage(p - 1, pfS, kslot);
+        if (sact) store_planes(p - 1, cv);
         MF_STAMP(4);
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): tile p has landed (and the epilogue's stores are out)
+        if (p < n_my) tile_max(p, pfL);
         MF_STAMP(6);
         rs_barrier();
         MF_STAMP(5);

@@ -550,6 +550,19 @@ GRHIP_API int grhip_pfb_channelizer_ccf_general_work_device(grhip_pfb_channelize
                                                             size_t stream_stride_items, void *d_out,
                                                             void *stream);
 
+/* The hier block blks2.pfb_channelizer_ccf (gnuradio-core/src/python/gnuradio/blks2impl/pfb_channelizer.py:25-75:
+ * gr_stream_to_streams -> gr_pfb_channelizer_ccf -> gr_vector_to_streams) as ONE call on the handle above: ONE
+ * interleaved input stream (general/gr_stream_to_streams.cc:57-63: stream j's item m is d_in[m * numchans + j]), numchans
+ * output streams (general/gr_vector_to_streams.cc:57-63: channel k's stream at d_out + k * out_stride_items, item t is
+ * bin k of output vector t).  d_in carries taps_per_filter * numchans history items in front (the channeliser's history
+ * of taps_per_filter + 1 on each of its inputs), zeros at the start of a flowgraph.  noutput_items and the return value are
+ * the inner block's (output vectors = items per output stream); results equal the three blocks run one after the other
+ * bit for bit.  Oversample rate 1 with 2 / 4 / 8 / 16 channels takes one fused kernel (16 B of memory traffic per
+ * sample instead of 48); every other shape runs the three kernels on work buffers of the handle. */
+GRHIP_API int grhip_pfb_channelizer_ccf_hier_work_device(grhip_pfb_channelizer_ccf *h, int noutput_items,
+                                                         const void *d_in, void *d_out, size_t out_stride_items,
+                                                         void *stream);
+
 /* ======================================================================
  * Full DMR chain as one device-resident pipeline (hier block):
  *   freq_xlating_fir_filter_ccc -> quadrature_demod_cf ->

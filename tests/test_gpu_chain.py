@@ -234,7 +234,7 @@ def test_chain_eight_captures_per_wave(gpu, po, wl, decim, ntaps, n_out, omega):
     assert np.array_equal(outs[8][0], outs[1][0]) and np.array_equal(outs[8][1], outs[1][1])
 
 
-@pytest.mark.parametrize("limit", [1, 7, 8, 9, 1003, 4096, 6999])
+@pytest.mark.parametrize("limit", [1, 7, 8, 9, 1003, 4096, 6900])
 def test_clock_recovery_stops_at_its_output_limit(gpu, po, wl, limit):
     """`oo < noutput_items` (digital_clock_recovery_mm_ff.cc:113) with a limit that is not a multiple of the
     eight symbols a pass of mm_rows_kernel takes: both forms of the loop stop at exactly `limit` symbols, with the

@@ -249,6 +249,46 @@ def test_pfb_tone_lands_in_its_channel_full_size(gpu, wl):
         assert np.argmax(p) == k and p[k] > 100 * np.delete(p, k).max()
 
 
+@pytest.mark.parametrize("M,tpf,osr,nout", [(8, 32, 1, 1), (8, 32, 1, 511), (8, 32, 1, 5000), (8, 16, 1, 513), (8, 40, 1, 2000),
+                                            (2, 24, 1, 3000), (4, 32, 1, 1025), (16, 8, 1, 1500), (16, 33, 1, 700),
+                                            (5, 12, 1, 900), (8, 16, 2, 1200), (32, 16, 1, 600), (12, 10, 3, 999)])
+def test_pfb_channelizer_hier_block_in_one_call(gpu, M, tpf, osr, nout):
+    """blks2.pfb_channelizer_ccf (blks2impl/pfb_channelizer.py:25-75): ONE interleaved stream in, M streams out, in one
+    call -- bit for bit what gr_stream_to_streams -> gr_pfb_channelizer_ccf -> gr_vector_to_streams give (the fused kernel
+    at oversample rate 1 and 2 / 4 / 8 / 16 channels; the three kernels behind the same entry for every other shape)"""
+    import torch
+    rng = np.random.default_rng(M * 100 + tpf)
+    taps = rng.uniform(-1, 1, M * tpf - (M // 2)).astype(np.float32)      # ceil(ntaps / M) = tpf, the last filter partly zero
+    pf = gpu.pfb_channelizer_ccf(M, taps, osr)
+    nout -= nout % pf.output_multiple()
+    nout = max(nout, pf.output_multiple())
+    assert pf.history() == tpf + 1
+    tc = int(np.rint(nout / osr))                                        # items consumed per stream
+    x = _rc(rng, tc * M)
+    xil = np.concatenate([np.zeros(tpf * M, np.complex64), x])            # taps_per_filter zeros of history on every stream
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    d_il = torch.from_numpy(xil.view(np.float32).reshape(-1, 2)).to(dev)
+    # the three blocks: stream j = items j, j + M, ... (gr_stream_to_streams.cc:57-63)
+    per = tpf + tc + 1
+    d_streams = torch.zeros((M, per, 2), dtype=torch.float32, device=dev)
+    d_streams[:, :tpf + tc] = d_il.reshape(-1, M, 2).permute(1, 0, 2)
+    d_vec = torch.zeros((nout, M, 2), dtype=torch.float32, device=dev)
+    assert pf.general_work_device(nout, d_streams, per, d_vec, st) == 0   # d_updated from the ctor's set_taps (.cc:169-172)
+    assert pf.general_work_device(nout, d_streams, per, d_vec, st) == nout
+    st.synchronize()
+    want = d_vec.permute(1, 0, 2).contiguous().cpu().numpy()            # gr_vector_to_streams: channel k = bin k of every vector
+    pf2 = gpu.pfb_channelizer_ccf(M, taps, osr)
+    stride = nout + 5
+    d_out = torch.full((M, stride, 2), 7.0, dtype=torch.float32, device=dev)
+    assert pf2.hier_work_device(nout, d_il, d_out, stride, st) == 0
+    assert pf2.hier_work_device(nout, d_il, d_out, stride, st) == nout
+    st.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[:, :nout].view(np.uint32), want.view(np.uint32))
+    assert (got[:, nout:] == 7.0).all()                                  # nothing behind the items produced
+
+
 @pytest.mark.parametrize("ntaps,decim", [(1, 1), (7, 1), (64, 2), (256, 4), (255, 5), (1000, 1), (2049, 3), (300, 16), (100, 8),
                                          (2500, 1)])      # > 2049 taps: the batched overlap-add path
 def test_fft_filter_ccc_vs_oracle_and_direct_form(gpu, po, ntaps, decim):

@@ -107,10 +107,13 @@ def test_amplitude_step_inside_a_tile(gpu, po, where):
     assert np.abs(got[quiet] - ref[quiet]).max() <= bound
     loud = np.arange(n) > where // decim + 1
     assert _per_element(got[loud], ref[loud]) <= TOL
-    # the f32 vector engine keeps the local precision
+    # FAST_VALU takes the overlap-save engine at this length: its error is relative to a 4096-sample block's peak
+    # (DESIGN 4.2), the same kind of bound; only the generic-order mode keeps the reference's local precision (bit for bit)
     blk.set_mode(gpu.MODE_FAST_VALU)
-    got_v = blk.work(n, x)
-    assert _per_element(got_v[quiet], ref[quiet]) <= TOL and _per_element(got_v[loud], ref[loud]) <= TOL
+    assert rel_err_max(blk.work(n, x), ref) <= TOL
+    blk.set_mode(gpu.MODE_GENERIC)
+    got_g = blk.work(n, x)
+    assert np.array_equal(got_g.view(np.uint32), ref.view(np.uint32))
 
 
 @pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
