@@ -43,6 +43,16 @@
 #include "grhip_internal.h"
 #include "mfma_tables.h"
 
+#ifndef GRHIP_LG_W2
+#define GRHIP_LG_W2 0
+#endif
+#ifndef GRHIP_LG_ACC3
+#define GRHIP_LG_ACC3 0
+#endif
+#ifndef GRHIP_LG_ORDER
+#define GRHIP_LG_ORDER 1
+#endif
+
 namespace grhip {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -354,11 +364,21 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                 const h16x2 rh = __builtin_convertvector(re, h16x2), ih = __builtin_convertvector(im, h16x2);
                 const h16x2 rlo = split_lo(re, rh), ilo = split_lo(im, ih);
                 if ((i + 1) * mf::ROUND <= SP || 2 * t + i * mf::ROUND < SP) {
+#if GRHIP_LG_W2
+                    // two stores per round, each to two planes a multiple of 256 bytes apart (round 3: the LDS store path
+                    // takes 2 cycles per source register: 6 + 6 instead of 4 x 4 per round)
+                    const int ad = st_off + i * ST_STEP;            // LDS byte address (dynamic LDS starts at 0)
+                    asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:0 offset1:%5\n\t"
+                                 "ds_write2st64_b32 %0, %3, %4 offset0:%6 offset1:%7"
+                                 :: "v"(ad), "v"(rh), "v"(rlo), "v"(ih), "v"(ilo),
+                                    "n"(PL / 256), "n"(2 * (PL / 256)), "n"(3 * (PL / 256)) : "memory");
+#else
                     unsigned char *d = dst + i * ST_STEP;
                     *reinterpret_cast<h16x2 *>(d) = rh;
                     *reinterpret_cast<h16x2 *>(d + PL) = rlo;
                     *reinterpret_cast<h16x2 *>(d + 2 * PL) = ih;
                     *reinterpret_cast<h16x2 *>(d + 3 * PL) = ilo;
+#endif
                 }
             }
         }
@@ -475,21 +495,48 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         h16x8 Bl_n = *reinterpret_cast<const h16x8 *>(chunk_ptr(0) + PL);
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
+#if GRHIP_LG_ACC3
+            // three accumulator tiles per block, added once at its end: the high-half products of the even and of the
+            // odd k-steps and the two low-half products.  An output then sees a third of the f32 accumulation roundings
+            // at about half the partial-sum magnitude: the FAST demodulator's per-element deviation from the reference
+            // went from 2.40e-5 to 1.74e-5 on cfg2 (round 3)
+            f32x4 m0{0.f, 0.f, 0.f, 0.f}, m1{0.f, 0.f, 0.f, 0.f}, lo{0.f, 0.f, 0.f, 0.f};
+#else
             acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+            // The k-steps of a block are taken from the band's ends towards its middle (0, KS-1, 1, KS-2, ...): a low-pass
+            // has its large taps in the middle, so the partial sum stays small until the last two or three k-steps and
+            // only those accumulations round at the output's magnitude (in index order every accumulation from the
+            // middle on does).  Same MFMAs, same registers; the FAST demodulator's largest per-element deviation from
+            // the reference on cfg2: 2.40e-5 in index order (round 3).
+            auto kstep = [](int q) constexpr { return GRHIP_LG_ORDER ? ((q & 1) ? KS - 1 - (q >> 1) : (q >> 1)) : q; };
 #pragma unroll
-            for (int j = 0; j < KS; ++j) {
+            for (int jq = 0; jq < KS; ++jq) {
+                const int j = kstep(jq);
                 const h16x8 Bh = Bh_n, Bl = Bl_n;
-                const int cn = j + 1 < KS ? CB * b + j + 1 : CB * (b + 1);       // next chunk: this block's, or the next block's first
-                if (j + 1 < KS || b + 1 < NBLK) {
+                const int cn = jq + 1 < KS ? CB * b + kstep(jq + 1) : CB * (b + 1) + kstep(0);       // next chunk: this block's, or the next block's first
+                if (jq + 1 < KS || b + 1 < NBLK) {
                     const unsigned char *src = chunk_ptr(cn);
                     Bh_n = *reinterpret_cast<const h16x8 *>(src);
                     Bl_n = *reinterpret_cast<const h16x8 *>(src + PL);
                 }
+#if GRHIP_LG_ACC3
+                // (the even / odd split only where the registers hold it without spilling: the headline shape and the short bands)
+                constexpr bool EVEN_ODD = GRHIP_LG_ACC3 == 1 && (KS <= 6 || (D == 4 && EPI == EPI_DEMOD));
+                if (EVEN_ODD && (j & 1)) m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh, m1, 0, 0, 0);
+                else m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh, m0, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bl, lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[j], Bh, lo, 0, 0, 0);
+#else
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bh, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bl, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[j], Bh, acc[b], 0, 0, 0);
-                if (j == 1) fetch(rsrc_n, voff_n, b);       // a quarter of the next tile's loads per block
+#endif
+                if (jq == 1) fetch(rsrc_n, voff_n, b);       // a quarter of the next tile's loads per block
             }
+#if GRHIP_LG_ACC3
+            acc[b] = GRHIP_LG_ACC3 == 1 ? (m0 + m1) + lo : m0 + lo;
+#endif
         }
         }
         MF_STAMP(4);
@@ -592,6 +639,7 @@ extern "C" __attribute__((visibility("default"))) int grdbg_set_stamp_buffer_mfm
 #endif
 
 
+#ifdef GRHIP_DIAG       // (diagnostic builds only: see launch_mfma_inst)
 // =================================================================================================
 // fir_mfma_rs_kernel -- the same engine with the waves of a workgroup in two ROLES (round 3)
 // =================================================================================================
@@ -619,6 +667,11 @@ extern "C" __attribute__((visibility("default"))) int grdbg_set_stamp_buffer_mfm
 // Accuracy: a block's 30 MFMAs go to three accumulators (Ah Xh of even / odd k-steps, the two
 // low-half products) that are added once at the end, so an output sees a third of the f32
 // accumulation roundings at half the partial-sum magnitude.
+// Diagnostic builds only (-DGRHIP_RS_ABL=mask, wrong results): 1 = no operand reads / MFMAs, 2 = no epilogue,
+// 4 = no conversion / plane stores, 8 = no tile loads, 16 = no block-floating-point maximum.  Which unit pins the period?
+#ifndef GRHIP_RS_ABL
+#define GRHIP_RS_ABL 0
+#endif
 namespace rs {
 constexpr int NSTG = 8, NMAT = mf::WAVES;
 constexpr int THREADS = 64 * (NSTG + NMAT);
@@ -676,6 +729,119 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
     const int n_my = (int)((total_tiles - blockIdx.x + Gd - 1) / Gd);
     const int P = n_my + 3;
 
+    // ---- shared by both roles ----
+    const int ts = t;                       // stager thread index (0 .. STG_T - 1 in the stager waves)
+    constexpr int OOB = 0x7ffffff0;
+    const int lead = a.off ^ (int)(a.n_lo & 1);
+    int *kring = reinterpret_cast<int *>(smem + R::OFF_MISC + 32);      // block-floating-point exponent of tile q at [q & 3]
+    auto decode = [&](int q, int &s_, int &b_) __attribute__((always_inline)) {
+        const unsigned id = blockIdx.x + (unsigned)q * Gd;
+        b_ = (int)(id / (unsigned)a.n_streams);
+        s_ = (int)(id - (unsigned)b_ * (unsigned)a.n_streams);
+    };
+    auto tile_geom = [&](int s, int b, __amdgpu_buffer_rsrc_t &rsrc, int &voff) __attribute__((always_inline)) {
+        const long long g0 = ((long long)b * NTE - BLK) * D - a.off - a.n_lo + lead;   // tile start relative to the descriptor
+        const float2 *x = a.x + (long long)s * a.x_stride + a.n_lo - lead;
+        const long long bytes = (a.n_in - a.n_lo + lead) * 8;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x), 0, (int)bytes, 0x00020000);
+        voff = (int)(g0 * 8) + 16 * ts;             // negative = before the stream: out of range, zeros
+    };
+    // ---- E: one 16-output block of a matrix wave's accumulator tiles (buffer q & 1): demodulator / rotator, stores.
+    // Blocks 2 and 3 of a matrix wave are finished by that wave itself right behind its accumulator stores (it would
+    // otherwise wait at the barrier); blocks 0 and 1 by the two stagers that belong to it, in the next period.
+    const int rsl = lane >> 3, r8 = lane & 7;
+    struct EpiRegs { f32x4 yv; f32x2 pv; };
+    auto epilogue_read = [&](int q, int mw, int b, EpiRegs &er) __attribute__((always_inline)) {
+        const int scw_u = mw * (mf::WAVE_NEW * D) + G::HALO;
+        const unsigned char *scr = smem + (q & 1) * R::BUF + 2 * scw_u + 32 * (scw_u >> LOGQ);
+        er.yv = *reinterpret_cast<const f32x4 *>(scr + b * PL + 4 * (rsl * SCR_SEG + 4 * r8));
+        er.pv = f32x2{0.f, 0.f};
+        if (DEMOD) {
+            // predecessor of a segment's first output of the block: row 15 of the block before, or -- block 0 --
+            // of the last block of the segment before (the wave's first segment has none: its block 0 is overlap)
+            const int pb = b == 0 ? NBLK - 1 : b - 1;
+            const int ps = b == 0 ? (rsl > 0 ? rsl - 1 : 0) : rsl;
+            er.pv = *reinterpret_cast<const f32x2 *>(scr + pb * PL + 4 * (ps * SCR_SEG + 30));
+        }
+    };
+    auto epilogue_block = [&](int q, int kx, int mw, int b, bool carry_out, const EpiRegs &er) __attribute__((always_inline)) {
+        int s, bidx;
+        decode(q, s, bidx);
+        const float inv_scale = __builtin_amdgcn_ldexpf(1.0f, -kx - a.kexp);
+        // the carry of the previous call, for the stream's first tile (frame of the composite FIR output,
+        // fir_kernels.h), brought into this tile's frame and scale
+        float ypfx = 0.f, ypfy = 0.f;
+        if (DEMOD && bidx == 0 && b == 1 && a.y_prev) {
+            const float2 yp = a.y_prev[s];
+            const float2 vm = a.vtab[BLK - 1];
+            const float2 qq = cmul_fma(yp, make_float2(vm.x, -vm.y));
+            const float sc2 = __builtin_amdgcn_ldexpf(1.0f, kx + a.kexp);
+            ypfx = qq.x * sc2; ypfy = qq.y * sc2;
+        }
+        __amdgpu_buffer_rsrc_t orsrc, grsrc;
+        if (DEMOD) {
+            orsrc = __builtin_amdgcn_make_buffer_rsrc(a.d_out + (long long)s * a.d_stride, 0, (int)(a.n_out * 4), 0x00020000);
+        } else {
+            orsrc = __builtin_amdgcn_make_buffer_rsrc(a.y_out + (long long)s * a.y_stride, 0, (int)(a.n_out * 8), 0x00020000);
+            if (ROT) grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.gtab), 0, (int)(a.n_out * 8), 0x00020000);
+        }
+        const int jt = mw * mf::WAVE_NEW + rsl * mf::SEG_OUT + 2 * r8;       // tile-local index of the lane's first output of block 0
+        const int n_base = bidx * NTE - BLK + jt;                          // its stream index; < 2^28
+        {
+            const float y0x = er.yv[0], y0y = er.yv[1], y1x = er.yv[2], y1y = er.yv[3];
+            const int n = n_base + BLK * b;
+            const bool own = !(b == 0 && rsl == 0) && n >= 0;       // the wave's overlap block stores nothing
+            if (DEMOD) {
+                float px = dpp_row<0x111>(y1x), py = dpp_row<0x111>(y1y);      // row_shr:1: the lane before, same segment
+                const bool from_carry = bidx == 0 && mw == 0 && b == 1 && rsl == 0;    // output 0 of the stream
+                const float qx = from_carry ? ypfx : er.pv[0], qy = from_carry ? ypfy : er.pv[1];
+                px = r8 == 0 ? qx : px;
+                py = r8 == 0 ? qy : py;
+                const float d0 = quad_demod_fast(make_float2(y0x, y0y), make_float2(px, py), a.gain, s_atan);
+                const float d1 = quad_demod_fast(make_float2(y1x, y1y), make_float2(y0x, y0y), a.gain, s_atan);
+                const f32x2 dd{d0, d1};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, dd), orsrc, own ? 4 * n : OOB, 0, 0);
+            } else {
+                float2 o0 = make_float2(y0x, y0y), o1 = make_float2(y1x, y1y);
+                if (PREMIX) {
+                    const float4 vv = *reinterpret_cast<const float4 *>(a.vtab + jt + BLK * b);   // e^{-jw j D}
+                    o0 = cmul_fma(o0, make_float2(vv.x, vv.y));
+                    o1 = cmul_fma(o1, make_float2(vv.z, vv.w));
+                }
+                o0.x *= inv_scale; o0.y *= inv_scale; o1.x *= inv_scale; o1.y *= inv_scale;
+                if (ROT) {
+                    const u32x4 gv = __builtin_amdgcn_raw_buffer_load_b128(grsrc, own ? 8 * n : OOB, 0, 0);
+                    const f32x4 gq = __builtin_bit_cast(f32x4, gv);
+                    o0 = cmul_ref(o0, make_float2(gq[0], gq[1]));                   // gr_rotator: z = in * d_phase
+                    o1 = cmul_ref(o1, make_float2(gq[2], gq[3]));
+                }
+                const f32x2 oa{o0.x, o0.y}, ob{o1.x, o1.y};
+                const int so = own ? 8 * n : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oa), orsrc, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), orsrc, so + 8, 0, 0);
+            }
+        }
+        // carry for the next call: the composite FIR output of the stream's last output, computed directly (f32,
+        // composite taps) by the wave the caller names, for the stream's last tile
+        if (carry_out && DEMOD && a.y_last && bidx == tiles_per_stream - 1) {
+            const long long item0 = (a.n_out - 1) * D - a.n_lo + lead;       // relative to the stream's descriptor
+            __amdgpu_buffer_rsrc_t xr; int vdummy;
+            tile_geom(s, bidx, xr, vdummy);
+            float sx = 0.f, sy = 0.f;
+            for (int i = lane; i < a.T; i += 64) {
+                const long long it = item0 + i;
+                const int vo = (it < 0 || (lead && it == 0)) ? OOB : (int)(it * 8);
+                const u32x2 xv = __builtin_amdgcn_raw_buffer_load_b64(xr, vo, 0, 0);
+                const f32x2 xf = __builtin_bit_cast(f32x2, xv);
+                const float2 c = a.ctaps[i];
+                sx = __builtin_fmaf(c.x, xf.x, sx); sx = __builtin_fmaf(-c.y, xf.y, sx);
+                sy = __builtin_fmaf(c.x, xf.y, sy); sy = __builtin_fmaf(c.y, xf.x, sy);
+            }
+            sx = wave_sum_f(sx); sy = wave_sum_f(sy);
+            if (lane == 0) a.y_last[s] = make_float2(sx, sy);
+        }
+    };
+
     if (w >= rs::NSTG) {
         // =============================== matrix role ===============================
         const int mw = w - rs::NSTG;
@@ -707,7 +873,7 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
 
         MF_STAMP_DECL;
         constexpr int NCH = G::NCH;                   // operand chunks of a segment; chunk c is k-step c - CB b of block b
-        constexpr int PDK = (D == 2 && KS > 6) ? 1 : rs::PD;     // (decimation 2, long band: every block is live at once, one chunk ahead fits the registers)
+        constexpr int PDK = KS > 6 ? 1 : rs::PD;     // (long band: A takes 80 registers, one chunk ahead is what fits beside the wave's share of the epilogue)
         for (int p = 0; p < P; ++p) {
             const bool act = p >= 2 && p - 2 < n_my;
             unsigned char *buf = smem + (p & 1) * R::BUF;
@@ -723,7 +889,7 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
                 Bl[c % (PDK + 1)] = *reinterpret_cast<const h16x8 *>(src + PL);
             };
             auto half = [&](int h) __attribute__((always_inline)) {
-                constexpr int HC = NCH / 2;
+                constexpr int HC = NCH / 8;               // barrier A comes early in the period (the stagers only read their accumulator tiles in front of it)
                 if (h == 0) {
 #pragma unroll
                     for (int b = 0; b < NBLK; ++b) {
@@ -762,12 +928,16 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
                 }
             };
             MF_STAMP(7);
-            if (act) half(0);
+            if (act && !(GRHIP_RS_ABL & 1)) half(0);
             MF_STAMP(0);
             rs_barrier();
             MF_STAMP(3);
             if (act) {
-                half(1);
+                if (!(GRHIP_RS_ABL & 1)) half(1);
+                else {
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) { m0[b] = f32x4{0.f, 0.f, 0.f, 0.f}; m1[b] = m0[b]; lo[b] = m0[b]; }
+                }
                 // accumulator layout in ([segment][row][re, im]): block b into plane b of the wave's own stretch
                 // (nobody else reads it: Geo::HALO), read by the stagers after the next barrier
 #pragma unroll
@@ -776,6 +946,16 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
                     float *sb = reinterpret_cast<float *>(buf + scw_off + b * PL);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sb[sc_wr + 2 * i] = accf[i];
+                }
+                // blocks 2 and 3 straight away (own tiles only: LDS keeps a wave's operations in order)
+                const int q = p - 2;
+                const int kx = kring[q & 3];
+#pragma unroll
+                for (int b = 2; b < NBLK; ++b) {
+                    if (GRHIP_RS_ABL & 2) break;
+                    EpiRegs er;
+                    epilogue_read(q, mw, b, er);
+                    epilogue_block(q, kx, mw, b, false, er);
                 }
             }
             MF_STAMP(4);
@@ -787,7 +967,6 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
     }
 
     // =============================== stager role ===============================
-    const int ts = t;                       // 0 .. STG_T - 1
     MF_STAMP_DECL;
 #if defined(GRHIP_RS_PRIO) && GRHIP_RS_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
@@ -814,21 +993,6 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
     // staging store: sample u = 2 ts + ROUND i  ->  byte 2u + 32 (u >> LOGQ) of each plane
     const int st_off = 4 * ts + 32 * ((2 * ts) >> LOGQ);
     constexpr int ST_STEP = 2 * rs::ROUND + 32 * (rs::ROUND >> LOGQ);
-    constexpr int OOB = 0x7ffffff0;
-    const int lead = a.off ^ (int)(a.n_lo & 1);
-
-    auto decode = [&](int q, int &s_, int &b_) __attribute__((always_inline)) {
-        const unsigned id = blockIdx.x + (unsigned)q * Gd;
-        b_ = (int)(id / (unsigned)a.n_streams);
-        s_ = (int)(id - (unsigned)b_ * (unsigned)a.n_streams);
-    };
-    auto tile_geom = [&](int s, int b, __amdgpu_buffer_rsrc_t &rsrc, int &voff) __attribute__((always_inline)) {
-        const long long g0 = ((long long)b * NTE - BLK) * D - a.off - a.n_lo + lead;   // tile start relative to the descriptor
-        const float2 *x = a.x + (long long)s * a.x_stride + a.n_lo - lead;
-        const long long bytes = (a.n_in - a.n_lo + lead) * 8;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(x), 0, (int)bytes, 0x00020000);
-        voff = (int)(g0 * 8) + 16 * ts;             // negative = before the stream: out of range, zeros
-    };
     // the item in front of a stream that does not start on a 16-byte boundary (lead = 1: the descriptor starts one
     // item early) reads as zero: it sits in the first tile's round 0 (the tile starts BLK D + off + n_lo - lead < ROUND
     // samples before the stream's first item) and is dropped where the values are used, not in the registers
@@ -842,21 +1006,41 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         return b == 0 && voff == 0;
     };
 
-    // ---- L: the tile's loads, rounds [i0, i1), into one of the two register sets ----
-    auto issue_loads = [&](int q, f32x4 (&pf)[NI], int i0, int i1) __attribute__((always_inline)) {
-        if (q >= n_my) return;
+    // ---- L: the tile's loads into one of the two register sets.  Hand-issued (inline asm) and hand-waited: a set is
+    // loaded in one trip of the period loop and used in the next, and for such loads hipcc 7.2's wait-count bookkeeping
+    // falls back to "all but the youngest 8 ... 0 operations" at the first use -- it drained the loads that had just been
+    // issued (or, with the request at the period's start, let nothing fly across the loop's back edge).  The compiler
+    // does not know these registers have writes pending: every use sits behind loads_landed() below, which waits
+    // (vmcnt counts in order: leaving the `younger` most recent operations in flight) and redefines the registers for it.
+    struct LoadCtx { u32x4 rs; int voff; };
+    auto load_ctx = [&](int q) __attribute__((always_inline)) -> LoadCtx {
         int s, b;
         decode(q, s, b);
-        __amdgpu_buffer_rsrc_t rsrc; int voff;
-        tile_geom(s, b, rsrc, voff);
+        const long long g0 = ((long long)b * NTE - BLK) * D - a.off - a.n_lo + lead;
+        const unsigned long long xb = (unsigned long long)(a.x + (long long)s * a.x_stride + a.n_lo - lead);
+        LoadCtx c;                                   // the words __builtin_amdgcn_make_buffer_rsrc(x, 0, bytes, 0x00020000) holds
+        c.rs[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+        c.rs[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(xb >> 32) & 0xffffu));
+        c.rs[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)((a.n_in - a.n_lo + lead) * 8));
+        c.rs[3] = 0x00020000u;
+        c.voff = (int)(g0 * 8) + 16 * ts;
+        return c;
+    };
+    auto issue_round = [&](const LoadCtx &c, f32x4 &dst, int i) __attribute__((always_inline)) {
+        int vo = c.voff + i * (16 * rs::STG_T);
+        if ((i + 1) * rs::ROUND > SP && 2 * ts + i * rs::ROUND >= SP) vo = 0x7ffff000;   // past the tile: no traffic
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(vo), "s"(c.rs));
+    };
+    auto issue_loads = [&](int q, f32x4 (&pf)[NI]) __attribute__((always_inline)) {
+        const LoadCtx c = load_ctx(q);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (i < i0 || i >= i1) continue;
-            int vo = voff + i * (16 * rs::STG_T);
-            if ((i + 1) * rs::ROUND > SP && 2 * ts + i * rs::ROUND >= SP) vo = 0x7ffff000;   // past the tile: no traffic
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
-            pf[i] = __builtin_bit_cast(f32x4, v);
-        }
+        for (int i = 0; i < NI; ++i) issue_round(c, pf[i], i);
+    };
+    auto loads_landed = [&](f32x4 (&pf)[NI], bool younger_set) __attribute__((always_inline)) {
+        if (younger_set) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI));
+        else asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(pf[i]));
     };
     // ---- M: block floating point, the wave's largest |component| of the tile ----
     auto tile_max = [&](int q, f32x4 (&pf)[NI]) __attribute__((always_inline)) {
@@ -886,15 +1070,23 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
         if (lane == 0) wmax[w] = m;
     };
     // ---- C: registers -> (pre-mix, scale, split) -> registers: the four binary16 pairs of every round (vector work) ----
-    auto convert = [&](int q, f32x4 (&pf)[NI], u32x4 (&cv)[NI], int &kslot) __attribute__((always_inline)) {
+    // ---- C + S: registers -> (pre-mix, scale, split) -> the four planes of buffer q & 1, round by round; behind every
+    // round (q_load >= 0) the same round of tile q_load is requested into the registers it has just left -- one load
+    // between two rounds of vector work instead of nine in a row, which held the wave at the memory pipeline's queue for
+    // 0.5-1 us per period.  Two stores per round, each to two planes a multiple of 256 bytes apart.
+    static_assert(PL % 256 == 0 && 3 * (PL / 256) < 256, "plane distance as a ds_write2st64_b32 offset");
+    auto convert = [&](int q, f32x4 (&pf)[NI], int &kslot, int q_load) __attribute__((always_inline)) {
+        const LoadCtx lc = load_ctx(q_load >= 0 ? q_load : q);
         float mt = wmax[0];
 #pragma unroll
         for (int i = 1; i < rs::NSTG; ++i) mt = __builtin_fmaxf(mt, wmax[i]);
         int k = 14 - __builtin_amdgcn_frexp_expf(mt);   // |x| e^{jw} components stay below 2^15
         k = k > 100 ? 100 : (k < -100 ? -100 : k);
         kslot = k;
+        if (ts == 0) kring[q & 3] = k;                  // for the matrix waves' share of the epilogue (a period later)
         const float scale = __builtin_amdgcn_ldexpf(1.0f, k);
         const bool lz = lead_item_here(q);
+        const int base = (q & 1) * R::BUF + st_off;     // LDS byte address (dynamic LDS starts at 0)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             f32x2 e0{pf[i][0], pf[i][1]}, e1{pf[i][2], pf[i][3]};
@@ -906,125 +1098,16 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
             h16x2 rh, rlo, ih, ilo;
             split_scaled(e0.x, e1.x, scale, rh, rlo);
             split_scaled(e0.y, e1.y, scale, ih, ilo);
-            cv[i] = u32x4{__builtin_bit_cast(unsigned, rh), __builtin_bit_cast(unsigned, rlo), __builtin_bit_cast(unsigned, ih),
-                          __builtin_bit_cast(unsigned, ilo)};
-        }
-    };
-    // ---- S: the converted rounds into the four planes of buffer q & 1 (LDS store path only: two stores per round,
-    //      each to two planes a multiple of 256 bytes apart) ----
-    static_assert(PL % 256 == 0 && 3 * (PL / 256) < 256, "plane distance as a ds_write2st64_b32 offset");
-    auto store_planes = [&](int q, const u32x4 (&cv)[NI]) __attribute__((always_inline)) {
-        const int base = (q & 1) * R::BUF + st_off;                 // LDS byte address (dynamic LDS starts at 0)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
             if ((i + 1) * rs::ROUND <= SP || 2 * ts + i * rs::ROUND < SP) {
                 const int ad = base + i * ST_STEP;
                 asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:0 offset1:%5\n\t"
                              "ds_write2st64_b32 %0, %3, %4 offset0:%6 offset1:%7"
-                             :: "v"(ad), "v"(cv[i][0]), "v"(cv[i][1]), "v"(cv[i][2]), "v"(cv[i][3]),
+                             :: "v"(ad), "v"(rh), "v"(rlo), "v"(ih), "v"(ilo),
                                 "n"(PL / 256), "n"(2 * (PL / 256)), "n"(3 * (PL / 256)) : "memory");
             }
+            if (q_load >= 0) issue_round(lc, pf[i], i);
         }
     };
-    // ---- E: two of the four blocks of matrix wave w / 2, from its accumulator tiles in buffer q & 1 ----
-    const int rsl = lane >> 3, r8 = lane & 7;
-    auto epilogue = [&](int q, int kx) __attribute__((always_inline)) {
-        int s, bidx;
-        decode(q, s, bidx);
-        const int mw = w >> 1, b0 = (w & 1) * (NBLK / 2);
-        const int scw_u = mw * (mf::WAVE_NEW * D) + G::HALO;
-        const unsigned char *scr = smem + (q & 1) * R::BUF + 2 * scw_u + 32 * (scw_u >> LOGQ);
-        const float inv_scale = __builtin_amdgcn_ldexpf(1.0f, -kx - a.kexp);
-        // the carry of the previous call, for the stream's first tile (frame of the composite FIR output,
-        // fir_kernels.h), brought into this tile's frame and scale
-        float ypfx = 0.f, ypfy = 0.f;
-        if (DEMOD && bidx == 0 && a.y_prev) {
-            const float2 yp = a.y_prev[s];
-            const float2 vm = a.vtab[BLK - 1];
-            const float2 qq = cmul_fma(yp, make_float2(vm.x, -vm.y));
-            const float sc2 = __builtin_amdgcn_ldexpf(1.0f, kx + a.kexp);
-            ypfx = qq.x * sc2; ypfy = qq.y * sc2;
-        }
-        __amdgpu_buffer_rsrc_t orsrc, grsrc;
-        if (DEMOD) {
-            orsrc = __builtin_amdgcn_make_buffer_rsrc(a.d_out + (long long)s * a.d_stride, 0, (int)(a.n_out * 4), 0x00020000);
-        } else {
-            orsrc = __builtin_amdgcn_make_buffer_rsrc(a.y_out + (long long)s * a.y_stride, 0, (int)(a.n_out * 8), 0x00020000);
-            if (ROT) grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.gtab), 0, (int)(a.n_out * 8), 0x00020000);
-        }
-        const int jt = mw * mf::WAVE_NEW + rsl * mf::SEG_OUT + 2 * r8;       // tile-local index of the lane's first output of block 0
-        const int n_base = bidx * NTE - BLK + jt;                          // its stream index; < 2^28
-        f32x4 yv[NBLK / 2];
-        f32x2 pv[NBLK / 2];
-#pragma unroll
-        for (int bb = 0; bb < NBLK / 2; ++bb) {
-            const int b = b0 + bb;
-            yv[bb] = *reinterpret_cast<const f32x4 *>(scr + b * PL + 4 * (rsl * SCR_SEG + 4 * r8));
-            if (DEMOD) {
-                // predecessor of a segment's first output of the block: row 15 of the block before, or -- block 0 --
-                // of the last block of the segment before (the wave's first segment has none: its block 0 is overlap)
-                const int pb = b == 0 ? NBLK - 1 : b - 1;
-                const int ps = b == 0 ? (rsl > 0 ? rsl - 1 : 0) : rsl;
-                pv[bb] = *reinterpret_cast<const f32x2 *>(scr + pb * PL + 4 * (ps * SCR_SEG + 30));
-            }
-        }
-#pragma unroll
-        for (int bb = 0; bb < NBLK / 2; ++bb) {
-            const int b = b0 + bb;
-            const float y0x = yv[bb][0], y0y = yv[bb][1], y1x = yv[bb][2], y1y = yv[bb][3];
-            const int n = n_base + BLK * b;
-            const bool own = !(b == 0 && rsl == 0) && n >= 0;       // the wave's overlap block stores nothing
-            if (DEMOD) {
-                float px = dpp_row<0x111>(y1x), py = dpp_row<0x111>(y1y);      // row_shr:1: the lane before, same segment
-                const bool from_carry = bidx == 0 && mw == 0 && b == 1 && rsl == 0;    // output 0 of the stream
-                const float qx = from_carry ? ypfx : pv[bb][0], qy = from_carry ? ypfy : pv[bb][1];
-                px = r8 == 0 ? qx : px;
-                py = r8 == 0 ? qy : py;
-                const float d0 = quad_demod_fast(make_float2(y0x, y0y), make_float2(px, py), a.gain, s_atan);
-                const float d1 = quad_demod_fast(make_float2(y1x, y1y), make_float2(y0x, y0y), a.gain, s_atan);
-                const f32x2 dd{d0, d1};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, dd), orsrc, own ? 4 * n : OOB, 0, 0);
-            } else {
-                float2 o0 = make_float2(y0x, y0y), o1 = make_float2(y1x, y1y);
-                if (PREMIX) {
-                    const float4 vv = *reinterpret_cast<const float4 *>(a.vtab + jt + BLK * b);   // e^{-jw j D}
-                    o0 = cmul_fma(o0, make_float2(vv.x, vv.y));
-                    o1 = cmul_fma(o1, make_float2(vv.z, vv.w));
-                }
-                o0.x *= inv_scale; o0.y *= inv_scale; o1.x *= inv_scale; o1.y *= inv_scale;
-                if (ROT) {
-                    const u32x4 gv = __builtin_amdgcn_raw_buffer_load_b128(grsrc, own ? 8 * n : OOB, 0, 0);
-                    const f32x4 gq = __builtin_bit_cast(f32x4, gv);
-                    o0 = cmul_ref(o0, make_float2(gq[0], gq[1]));                   // gr_rotator: z = in * d_phase
-                    o1 = cmul_ref(o1, make_float2(gq[2], gq[3]));
-                }
-                const f32x2 oa{o0.x, o0.y}, ob{o1.x, o1.y};
-                const int so = own ? 8 * n : OOB;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oa), orsrc, so, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), orsrc, so + 8, 0, 0);
-            }
-        }
-        // carry for the next call: the composite FIR output of the stream's last output, computed directly (f32,
-        // composite taps) by the first stager of the workgroup that owns the stream's last tile
-        if (DEMOD && a.y_last && bidx == tiles_per_stream - 1 && w == 0) {
-            const long long item0 = (a.n_out - 1) * D - a.n_lo + lead;       // relative to the stream's descriptor
-            __amdgpu_buffer_rsrc_t xr; int vdummy;
-            tile_geom(s, bidx, xr, vdummy);
-            float sx = 0.f, sy = 0.f;
-            for (int i = lane; i < a.T; i += 64) {
-                const long long it = item0 + i;
-                const int vo = (it < 0 || (lead && it == 0)) ? OOB : (int)(it * 8);
-                const u32x2 xv = __builtin_amdgcn_raw_buffer_load_b64(xr, vo, 0, 0);
-                const f32x2 xf = __builtin_bit_cast(f32x2, xv);
-                const float2 c = a.ctaps[i];
-                sx = __builtin_fmaf(c.x, xf.x, sx); sx = __builtin_fmaf(-c.y, xf.y, sx);
-                sy = __builtin_fmaf(c.x, xf.y, sy); sy = __builtin_fmaf(c.y, xf.x, sy);
-            }
-            sx = wave_sum_f(sx); sy = wave_sum_f(sy);
-            if (lane == 0) a.y_last[s] = make_float2(sx, sy);
-        }
-    };
-
     // one period: pfL takes the loads of tile p, pfS holds tile p - 1 (complete: every period ends with the wave's
     // vector-memory counter at zero, and its maxima were published before the last barrier); kslot: the exponent of
     // tile p - 3 on entry (the epilogue's), of tile p - 1 on exit.
@@ -1038,39 +1121,58 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
     // compiler's counter bookkeeping understands (__builtin_amdgcn_s_waitcnt): a set that is loaded in one trip of the
     // loop and used in the next makes hipcc 7.2 wait for "all but the 8 youngest" operations at the first use, i.e.
     // for the loads just issued.
-    constexpr int LA = (NI + 1) / 2;            // rounds requested at the period's start, the rest behind the epilogue
+    // One period (pfL: tile p, in flight; pfS: tile p - 1, complete; kslot: the exponent of tile p - 3 on entry -- the
+    // epilogue's --, of tile p - 1 on exit):
+    //   the wave's block of tile p - 3 out of the accumulator tiles (LDS reads)
+    //   -- barrier A: from here the planes of buffer (p-1)&1 may be written --
+    //   that block's demodulator / stores; tile p - 1 converted and stored round by round, tile p + 1 requested round by
+    //   round into the registers that come free; wait for tile p (leaving tile p + 1 in flight), its maxima
+    //   -- barrier B --
+    // Tile p + 1's loads fly for a period and a half; some tile's loads are in flight at every moment.
     auto period = [&](int p, f32x4 (&pfL)[NI], f32x4 (&pfS)[NI], int &kslot) __attribute__((always_inline)) {
         MF_STAMP(7);
-        // (the rotate epilogue has loads of its own -- rotator phases -- which the in-order counter would make wait
-        // for the tile loads issued in front of them)
-        if (!ROT) issue_loads(p, pfL, 0, LA);
+        static_assert(NBLK == 4 && rs::NSTG == 2 * rs::NMAT, "stager w finishes block w & 1 of matrix wave w / 2");
+        const bool eact = p >= 3 && p - 3 < n_my && !(GRHIP_RS_ABL & 2);
+        const int kx = kslot;
+        EpiRegs er;
+        if (eact) epilogue_read(p - 3, w >> 1, w & 1, er);
         MF_STAMP(0);
-        if (p >= 3 && p - 3 < n_my) epilogue(p - 3, kslot);
-        if (ROT) issue_loads(p, pfL, 0, LA);
-        issue_loads(p, pfL, LA, NI);
-        MF_STAMP(1);
-        const bool sact = p >= 1 && p - 1 < n_my;
-        u32x4 cv[NI];
-        if (sact) convert(p - 1, pfS, cv, kslot);
-        MF_STAMP(2);
         rs_barrier();
         MF_STAMP(3);
-        if (sact) store_planes(p - 1, cv);
+        // Half of the stagers convert first and finish their block of the epilogue afterwards, the other half the other
+        // way round: the CU's loads (requested round by round inside the conversion) are then spread over the whole
+        // period.  With all eight stagers in step the requests came in one burst per period, the memory pipeline's queue
+        // ran empty between two bursts, and transfer time and vector time ADDED UP (compute alone 0.83 ms, loads alone
+        // 0.80 ms, both 1.28 ms per 64 x 10 M samples).
+        const bool sact = p >= 1 && p - 1 < n_my;
+        const bool lact = p + 1 < n_my && !(GRHIP_RS_ABL & 8);
+        const bool convert_first = (w & 4) == 0;
+        if (!convert_first && eact) epilogue_block(p - 3, kx, w >> 1, w & 1, w == 0, er);
+        MF_STAMP(1);
+        if (sact && !(GRHIP_RS_ABL & 4)) convert(p - 1, pfS, kslot, lact ? p + 1 : -1);   // (pfS becomes tile p + 1's set)
+        else if (lact) issue_loads(p + 1, pfS);
+        MF_STAMP(2);
+        if (convert_first && eact) epilogue_block(p - 3, kx, w >> 1, w & 1, w == 0, er);
         MF_STAMP(4);
-        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): tile p has landed (and the epilogue's stores are out)
-        if (p < n_my) tile_max(p, pfL);
+        if (p < n_my) {
+            loads_landed(pfL, lact);                // tile p is there; tile p + 1 stays in flight
+            if (!(GRHIP_RS_ABL & 16)) tile_max(p, pfL);
+        }
         MF_STAMP(6);
         rs_barrier();
         MF_STAMP(5);
     };
     f32x4 pf0[NI], pf1[NI];
     int k0 = 0, k1 = 0;
+    if (!(GRHIP_RS_ABL & 8)) issue_loads(0, pf0);
     for (int p = 0; p < P; p += 2) {
         period(p, pf0, pf1, k1);
         if (p + 1 < P) period(p + 1, pf1, pf0, k0);
     }
     MF_STAMP_OUT(rs::NSTG + rs::NMAT);
 }
+
+#endif  // GRHIP_DIAG
 
 static int g_mf_cus = 0;
 
@@ -1094,10 +1196,14 @@ static int launch_mfma_inst(const FirMfmaArgs &a, hipStream_t st)
     // The role-split kernel (one 768-lane workgroup per CU, the whole register file) wherever the FIR has its CUs to
     // itself; a caller that runs another kernel on the same CUs (max_wg_per_cu = 1: the chain's clock recovery beside
     // the FIR on shared CUs) keeps the kernel above, which leaves half of every CU free.
-    bool role_split = a.max_wg_per_cu != 1;
-#ifdef GRHIP_DIAG       // diagnostic builds only: GRHIP_MF_RS=0 / 1 forces the choice (A/B runs)
-    if (const char *e = getenv("GRHIP_MF_RS")) role_split = atoi(e) != 0;
+    // The role-split kernel (fir_mfma_rs_kernel above: one 768-lane workgroup per CU, stager and matrix waves) exists in
+    // diagnostic builds only, selected with GRHIP_MF_RS=1: ten versions of it tied with or lost to the kernel above by 0-6 %
+    // (DESIGN 4.0a has the A/B table, the stamps and the ablations that say why).
+    bool role_split = false;
+#ifdef GRHIP_DIAG
+    if (const char *e = getenv("GRHIP_MF_RS")) role_split = atoi(e) != 0 && a.max_wg_per_cu != 1;
 #endif
+#ifdef GRHIP_DIAG
     if (role_split) {
         using R = GeoRS<D, KS>;
         auto kern_rs = fir_mfma_rs_kernel<D, KS, PREMIX, EPI>;
@@ -1112,6 +1218,8 @@ static int launch_mfma_inst(const FirMfmaArgs &a, hipStream_t st)
         GRHIP_HIP(hipGetLastError());
         return GRHIP_OK;
     }
+#endif
+    (void)role_split;
     int wgs = (160 * 1024) / (G::LDS + 256);
     if (wgs > 2) wgs = 2;
     if (a.max_wg_per_cu > 0 && wgs > a.max_wg_per_cu) wgs = a.max_wg_per_cu;

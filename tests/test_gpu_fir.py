@@ -693,9 +693,13 @@ def test_fast_demod_parity_numbers_cfg2(gpu, po, wl, mode_name, capsys):
         print("\n[%s] cfg2 demod parity: %s" % (mode_name, rep))
     assert rep["ok"]
     assert rep["steady_rel_inf"] <= 1e-5
-    # per element over |ref| > 0.1 max|ref|: an angle is as accurate as |dy| / |y| of the FIR output under it,
-    # which at 1e-6 (FIR) and |ref| down to a tenth of full scale bounds this at ~1e-5 x 10 in the worst
-    # case; measured: see the printed figure
-    assert rep["per_element_rel"] <= 3e-5
+    # per element over |ref| > 0.1 max|ref|.  Round 3 measured every party against the reference's formula in float64
+    # (tools/dbg/demod_attrib.py): the reference's generic build itself sits 8.8e-6 from it and 9.9e-6 from
+    # its own SSE build on this capture -- the 1e-5 per-element figure is the reference's reproducibility floor, which only a
+    # correctly rounded FIR (or the bit-exact GENERIC mode) can meet against the generic build.  What separates the
+    # FAST engines from it is the number of f32 accumulation roundings at full partial-sum magnitude: 256 sequential
+    # FMAs in the vector engine (2.42e-5), 30 MFMA accumulations into one tile in round 2 (2.40e-5), ten into each of
+    # three tiles that are added at the end since round 3 (1.74e-5).
+    assert rep["per_element_rel"] <= (2e-5 if mode_name == "MODE_FAST" else 3e-5)
     assert rep["step_exempted"] <= max(2, int(2e-5 * nout))
     assert rep["transient_rel_inf"] <= 1e-2

@@ -42,8 +42,8 @@ full = stamps.cpu().numpy().astype(np.float64).reshape(-1, NW, 10)
 tiles_total = B * ((nout + 1983) // 1984)
 per_wg = tiles_total / 256.0
 print("tiles per workgroup %.1f; periods = tiles + 3" % per_wg)
-names_s = ["issue loads", "epilogue", "wait loads + max", "barrier (mid)", "stage", "barrier (end)", "-", "loop"]
-names_m = ["blocks 0,1", "-", "-", "barrier (mid)", "blocks 2,3 + accumulators", "barrier (end)", "-", "loop"]
+names_s = ["accumulator tiles -> registers", "epilogue (one block)", "convert + plane stores + next loads", "barrier A", "-", "barrier B", "wait for the tile + maxima", "loop"]
+names_m = ["first chunks", "-", "-", "barrier A", "chunks + accumulators + two blocks of the epilogue", "barrier B", "-", "loop"]
 for role, waves, names in (("stager", range(0, 8), names_s), ("matrix", range(8, 12), names_m)):
     s = full[:, list(waves), :].reshape(-1, 10)
     s = s[s[:, :8].sum(1) > 0]
