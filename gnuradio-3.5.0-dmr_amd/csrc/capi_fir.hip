@@ -370,6 +370,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         a.sched = mf_sched.get();
         a.max_wg_per_cu = mf_wg_cap;
         a.max_cus = mf_cu_cap;
+        a.omega = omega;
         rc = launch_fir_mfma(decim, ntaps, true, demod ? EPI_DEMOD : EPI_ROTATE, a, st);
         if (rc) return rc;
         pos += n_out;

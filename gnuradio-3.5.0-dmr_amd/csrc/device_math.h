@@ -105,7 +105,11 @@ template <class Tab>
 __device__ __forceinline__ float quad_demod_fast(float2 cur, float2 prev, float gain, Tab tab)
 {
     const f32x2_t product = cmul_pk(f32x2_t{cur.x, cur.y}, f32x2_t{prev.x, -prev.y});
+#if defined(GRHIP_DIAG) && defined(GRHIP_PROBE) && (GRHIP_PROBE & 1)     // attribution probe: the IEEE divide in the FAST epilogue
+    return gain * fast_atan2f<true>(product.y, product.x, tab);
+#else
     return gain * fast_atan2f<false>(product.y, product.x, tab);
+#endif
 }
 
 // gr_branchless_clip (general/gr_math.h:63-69)

@@ -51,6 +51,9 @@ struct PfbArgs {
     // launch_pfb_hier only: `in` is the single interleaved stream (stream j's item m = in[m M + j], tpf M history items in front)
     float2 *out_streams = nullptr;      // channel k's stream at out_streams + k * out_stride
     long long out_stride = 0;
+    // pfb_os1_kernel's view of one sub-sequence of an integer-oversampled channeliser (filled in by launch_pfb)
+    int sub_r = 0, sub_os = 1, sub_q = 0, sub_last = 0;
+    long long in_items = 0;             // readable items per stream
 };
 int launch_pfb(const PfbArgs &a, hipStream_t st);
 // blks2's hier block in one pass (stream_to_streams -> pfb -> vector_to_streams); GRHIP_OK, < 0 on error, or -1 when

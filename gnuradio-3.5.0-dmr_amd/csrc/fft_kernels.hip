@@ -500,7 +500,16 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
                                                        // wave is done with its FIR (40 KB instead of 77 KB: 3 workgroups per CU)
     const int t = threadIdx.x, ln = t & 63;
     const int j = __builtin_amdgcn_readfirstlane(t >> 6);      // wave = stream: descriptors and taps stay scalar
-    const pfb_cfloat_p taps = (pfb_cfloat_p)(a.ftaps) + (size_t)(M - 1 - j) * a.tpf;
+    // Oversampled by an integer factor os = M / rate_ratio (round 3): output vectors t = os u + r, r fixed per launch, are a
+    // critically sampled channeliser of their own -- the commutator's `last` is the same for all of them
+    // (last_r = ((r + 1) rate_ratio - 1) mod M), stream j goes through filter (last_r - j) mod M at item u + q_r + (j <= last_r)
+    // into IFFT slot idxlut[j], one item further per u -- so the launcher runs this kernel os times.  os = 1: r = 0,
+    // last = M - 1, q = 0: filter and slot M - 1 - j, item u + 1, as before.
+    const int sub_last = a.sub_last, sub_os = a.sub_os;
+    const int fj = j <= sub_last ? sub_last - j : M + sub_last - j;
+    const int oj = a.sub_q + (j <= sub_last ? 1 : 0);
+    const int slot_j = sub_os == 1 ? M - 1 - j : __builtin_amdgcn_readfirstlane(a.idxlut[j]);
+    const pfb_cfloat_p taps = (pfb_cfloat_p)(a.ftaps) + (size_t)fj * a.tpf;
     const pfb_cfloat_p dft = (pfb_cfloat_p)(a.dft);
     float hres[NT ? R * NT : 1];
     if (NT) {
@@ -511,7 +520,7 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
     const __amdgpu_buffer_rsrc_t xr = IL
         ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.in), 0, (int)((a.nout + a.tpf) * 8 * M), 0x00020000)
         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.in + (long long)j * a.stride), 0,
-                                            (int)((a.nout + a.tpf) * 8), 0x00020000);
+                                            (int)(a.in_items * 8), 0x00020000);
     constexpr int OOB = (int)0xfffffff0;
     const int tot = TT + tpfp;
     pfb_f32x2 *dst = xs + (size_t)j * XS;
@@ -539,7 +548,7 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
             }
             return;
         }
-        const int vb = (int)((tile_ * TT + 1) * 8) + 8 * ln;
+        const int vb = (int)((tile_ * TT + oj) * 8) + 8 * ln;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             if (NT || 64 * i < tot) {
@@ -627,7 +636,7 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
         // ---- to IFFT slot M-1-j, transposed: sl[slot][t_local]
         __syncthreads();                               // sl aliases xs
         {
-            pfb_f32x2 *row = sl + (size_t)(M - 1 - j) * SS + ln * R + ln;
+            pfb_f32x2 *row = sl + (size_t)slot_j * SS + ln * R + ln;
 #pragma unroll
             for (int r = 0; r < R; ++r) row[r] = accv[r];
         }
@@ -693,7 +702,7 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
                     v[k] = acc;
                 }
             }
-            if (COAL) {
+            if (COAL && sub_os == 1) {
                 __syncthreads();                       // every wave has read its vectors' slots: the rows are free
                 pfb_f32x2 *sc = dst;                   // this wave's row, (M + 1) slots per vector
 #pragma unroll
@@ -719,7 +728,8 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
                 for (int k = 0; k < M; ++k) a.out_streams[(long long)k * a.out_stride + tt] = v[k];
                 continue;
             }
-            float2 *o = a.out + tt * M;
+            if (COAL && tt >= a.nout) continue;
+            float2 *o = a.out + (tt * sub_os + a.sub_r) * M;
             if (M % 2 == 0) {
                 float4 *o4 = reinterpret_cast<float4 *>(o);
 #pragma unroll
@@ -729,7 +739,7 @@ pfb_os1_kernel(const PfbArgs a, long long ntiles)
                 for (int k = 0; k < M; ++k) o[k] = v[k];          // (an odd vector is not a whole number of 16-byte pieces)
             }
         }
-        if (M != 8 || IL) __syncthreads();             // sl (= xs) belongs to the next tile's samples from here
+        if (M != 8 || IL || sub_os != 1) __syncthreads();   // sl (= xs) belongs to the next tile's samples from here
     }
 }
 
@@ -772,8 +782,10 @@ static int launch_pfb_os1_il(const PfbArgs &a, hipStream_t st)
     }
 }
 
-int launch_pfb_hier(const PfbArgs &a, hipStream_t st)
+int launch_pfb_hier(const PfbArgs &a_in, hipStream_t st)
 {
+    PfbArgs a = a_in;
+    a.sub_r = 0; a.sub_os = 1; a.sub_q = 0; a.sub_last = a.M - 1; a.in_items = a.nout + a.tpf;
     if (a.nout <= 0) return GRHIP_OK;
     if (a.rate_ratio != a.M || (((uintptr_t)a.in) & 15) || (((uintptr_t)a.out_streams) & 7)) return -1;
     switch (a.M) {
@@ -1106,10 +1118,47 @@ static int launch_pfb_fir_t(const PfbArgs &a, hipStream_t st)
     return launch_pfb_fir_t_tp<R, M, 0>(a, st);
 }
 
-int launch_pfb(const PfbArgs &a, hipStream_t st)
+int launch_pfb(const PfbArgs &a_in, hipStream_t st)
 {
+    PfbArgs a = a_in;
+    a.sub_r = 0; a.sub_os = 1; a.sub_q = 0; a.sub_last = a.M - 1; a.in_items = a.nout + a.tpf;
     if (a.nout <= 0) return GRHIP_OK;
     if (a.M < 1 || a.M > 1024) return fail(GRHIP_EINVAL, "numchans %d not supported on device", a.M);
+    // integer oversampling (os = M / rate_ratio) on the fast kernel's channel counts: os launches of pfb_os1_kernel, one per
+    // residue r of the output index (see the kernel); 0.08-0.13 of the HBM peak on pfb_rows_kernel before
+    if (a.rate_ratio > 0 && a.rate_ratio < a.M && a.M % a.rate_ratio == 0 && a.M <= 16 && (((uintptr_t)a.out) & 15) == 0) {
+        const int os = a.M / a.rate_ratio;
+        int rc = GRHIP_OK;
+        for (int r = 0; r < os && rc == GRHIP_OK; ++r) {
+            PfbArgs b = a;
+            b.sub_r = r; b.sub_os = os;
+            const long long c0 = (long long)(r + 1) * a.rate_ratio - 1;
+            b.sub_last = (int)(c0 % a.M); b.sub_q = (int)(c0 / a.M);
+            b.nout = (a.nout - r + os - 1) / os;
+            b.in_items = a.tpf + (a.nout * a.rate_ratio + a.M - 1) / a.M;
+            if (b.nout <= 0) continue;
+            rc = -1;
+            switch (a.M) {
+            case 2: rc = launch_pfb_os1<2>(b, st); break;
+            case 4: rc = launch_pfb_os1<4>(b, st); break;
+            case 8: rc = launch_pfb_os1<8>(b, st); break;
+            case 16: rc = launch_pfb_os1<16>(b, st); break;
+            case 3: rc = launch_pfb_os1_any<3>(b, st); break;
+            case 5: rc = launch_pfb_os1_any<5>(b, st); break;
+            case 6: rc = launch_pfb_os1_any<6>(b, st); break;
+            case 7: rc = launch_pfb_os1_any<7>(b, st); break;
+            case 9: rc = launch_pfb_os1_any<9>(b, st); break;
+            case 10: rc = launch_pfb_os1_any<10>(b, st); break;
+            case 11: rc = launch_pfb_os1_any<11>(b, st); break;
+            case 12: rc = launch_pfb_os1_any<12>(b, st); break;
+            case 13: rc = launch_pfb_os1_any<13>(b, st); break;
+            case 14: rc = launch_pfb_os1_any<14>(b, st); break;
+            case 15: rc = launch_pfb_os1_any<15>(b, st); break;
+            }
+            if (rc == -1 && r > 0) return fail(GRHIP_ERUNTIME, "pfb: sub-sequence launch refused after the first");
+        }
+        if (rc != -1) return rc;
+    }
     if (a.rate_ratio == a.M && (((uintptr_t)a.out) & 15) == 0) {
         int rc = -1;
         switch (a.M) {

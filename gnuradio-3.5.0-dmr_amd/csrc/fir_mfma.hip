@@ -353,9 +353,19 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
             for (int i = 0; i < NI; ++i) {
                 f32x2 e0{pf[i][0], pf[i][1]}, e1{pf[i][2], pf[i][3]};
                 if (PREMIX) {
+#if defined(GRHIP_DIAG) && defined(GRHIP_PROBE) && (GRHIP_PROBE & 2)
+                    // attribution probe: every sample's phasor from double precision instead of the product of two
+                    // binary32 phasors
+                    const double ang0 = a.omega * (double)(2 * t + mf::ROUND * i - a.off);
+                    const f32x2 p0{(float)cos(ang0) * scale, (float)sin(ang0) * scale};
+                    const f32x2 p1{(float)cos(ang0 + a.omega) * scale, (float)sin(ang0 + a.omega) * scale};
+                    e0 = cmul_pk(e0, p0);
+                    e1 = cmul_pk(e1, p1);
+#else
                     const f32x2 S{stab[2 * i], stab[2 * i + 1]};
                     e0 = cmul_pk(e0, cmul_pk(ws0, S));
                     e1 = cmul_pk(e1, cmul_pk(ws1, S));
+#endif
                 } else {
                     e0 = e0 * scale;
                     e1 = e1 * scale;

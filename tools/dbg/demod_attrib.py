@@ -92,6 +92,14 @@ def main():
         blk = g.xlating_demod(D, proto, c["center_freq"], c["fs"], gain)
         blk.set_mode(mode)
         rows[name] = blk.work(nout, xin)
+    if os.environ.get("COMPLEX_TAPS"):
+        # probe (iii): the complex-tap (non-pre-mix) engines -- a prototype whose imaginary parts are 1e-30 is "complex" for the
+        # dispatch and the same filter for the arithmetic; measured against the same yardstick and reference outputs
+        proto_c = (proto.real + 1j * np.float32(1e-30)).astype(np.complex64)
+        for name, mode in (("GPU FAST, complex-tap path", g.MODE_FAST), ("GPU FAST_VALU, complex-tap path", g.MODE_FAST_VALU)):
+            blk = g.xlating_demod(D, proto_c, c["center_freq"], c["fs"], gain)
+            blk.set_mode(mode)
+            rows[name] = blk.work(nout, xin)
     print("cfg2, %d samples; per element over |ref| > 0.1 max: max / rms / samples on the arctangent step" % n)
     for k, v in rows.items():
         print("  %-36s vs float64 yardstick: %.3e / %.3e / %d" % ((k,) + rel_figs(v, d64, gain)))
