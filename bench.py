@@ -377,7 +377,7 @@ def chain_bench(torch, g, wl, dev, proto, n, want_caps, reps=3):
     out["binary"] = timed(d_bits, nout)
     # ---- check ----
     nb = d_n.cpu().numpy()
-    flags_dev = int(((d_bits >> 1) & 1).sum(dtype=torch.int64).item())
+    flags_dev = int(torch.count_nonzero(d_bits & 2).item())
     n_syms_nominal = nout / c4["omega"]
     planted = len(range(100, int(n_syms_nominal) - 48, c4["sync_period_syms"]))
     chk = {"access_code_flags_on_device": flags_dev, "sync_words_planted": planted * S,

@@ -6,7 +6,7 @@ import numpy as np
 
 __all__ = [
     "GrhipError", "lib", "lib_path", "strerror", "device_count", "set_default_mode",
-    "MODE_FAST", "MODE_GENERIC", "MODE_FAST_VALU", "WORK_DONE",
+    "MODE_FAST", "MODE_GENERIC", "MODE_FAST_VALU", "MODE_FAST_REFTAPS", "WORK_DONE",
     "fir_filter_ccf", "fir_filter_fff", "fir_filter_ccc", "fir_filter_with_buffer",
     "freq_xlating_fir_filter_ccc", "quadrature_demod_cf", "xlating_demod",
     "clock_recovery_mm_ff", "clock_recovery_mm_cc", "binary_slicer_fb", "correlate_access_code_bb", "pager_slicer_fb", "unpack_k_bits_bb", "framer_sink_1", "framer_sink_1_batch", "stream_to_streams", "streams_to_stream", "vector_to_streams", "stream_to_vector", "head",
@@ -16,6 +16,7 @@ __all__ = [
 MODE_FAST = 0
 MODE_GENERIC = 1
 MODE_FAST_VALU = 2     # FAST without the matrix cores (vector FMAs only)
+MODE_FAST_REFTAPS = 3  # FAST + the reference's tap-angle quantisation reproduced by freq_xlating's matrix-core engine
 WORK_DONE = 0x7fffffff  # GRHIP_WORK_DONE: not an error, not an item count
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

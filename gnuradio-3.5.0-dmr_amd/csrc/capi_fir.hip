@@ -40,13 +40,16 @@ static int upload(DevBuf &b, const void *src, size_t bytes)
 
 // ---- operand tables of the matrix-core engine (mfma_tables.h) ---------------------
 // real taps c[k] multiplying x[nD + k]; both alignment parities
-static int build_mfma_taps(const float *c, int T, int D, DevBuf (&dA)[2], int *kexp)
+// fwT0 != 0: freq_xlating's pre-mix form -- the table carries the correction band G of the reference's tap-angle
+// quantisation behind A (mfma_tables.h); 0: plain real taps (gr_fir_ccf), G all zero
+static int build_mfma_taps(const float *c, int T, int D, DevBuf (&dA)[2], int *kexp, float fwT0 = 0.f)
 {
     const int KS = mf::ksteps_inst(D, T);
     *kexp = mf::tap_scale_exp(c, T);
     for (int off = 0; off < 2; ++off) {
         std::vector<uint16_t> A;
         mf::build_A(c, T, D, KS, off, *kexp, A);
+        mf::build_G(c, T, D, KS, off, *kexp, fwT0, A);
         int rc = upload(dA[off], A.data(), A.size() * sizeof(uint16_t));
         if (rc) return rc;
     }
@@ -165,7 +168,7 @@ int XlatingCore::build(int device)
         // pre-mix form on the matrix cores: x'[u] = x[u] e^{jw(u - off)}, real prototype taps
         std::vector<float> pr(ntaps);
         for (int i = 0; i < ntaps; ++i) pr[i] = proto[i].real();
-        rc = build_mfma_taps(pr.data(), ntaps, decim, d_mf_A, &mf_kexp);
+        rc = build_mfma_taps(pr.data(), ntaps, decim, d_mf_A, &mf_kexp, fwT0);
         if (rc) return rc;
         const int KS = mf::ksteps_inst(decim, ntaps);
         for (int off = 0; off < 2; ++off) {
@@ -371,6 +374,7 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
         a.max_wg_per_cu = mf_wg_cap;
         a.max_cus = mf_cu_cap;
         a.omega = omega;
+        a.tapq = mode == GRHIP_MODE_FAST_REFTAPS;
         rc = launch_fir_mfma(decim, ntaps, true, demod ? EPI_DEMOD : EPI_ROTATE, a, st);
         if (rc) return rc;
         pos += n_out;

@@ -92,6 +92,7 @@ struct FirMfmaArgs {
     int max_wg_per_cu;      // 0: as many as fit (2); 1: leave half of every CU to a kernel running beside this one
     int max_cus;            // 0: the device's; else the CUs the stream may use (a stream with a CU mask)
     double omega;           // PREMIX: the angle step (read by the attribution probe of diagnostic builds only)
+    int tapq;               // PREMIX: 1 = also the correction band of the reference's tap-angle quantisation (GRHIP_MODE_FAST_REFTAPS)
 };
 bool mfma_supported(int decim, int ntaps);
 int launch_fir_mfma(int decim, int ntaps, bool premix, int epi, const FirMfmaArgs &a, hipStream_t st);

@@ -53,6 +53,7 @@
 #define GRHIP_LG_ORDER 1
 #endif
 
+
 namespace grhip {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -84,7 +85,8 @@ template <int D, int KS> struct Geo {
     static constexpr int HALO = NCH * mf::CHUNK - (mf::SEGS * mf::SEG_OUT - mf::WAVE_NEW) * D - (mf::SEGS - 1) * 0;
     static constexpr int OFF_ATAN = 4 * PL;
     static constexpr int OFF_MISC = OFF_ATAN + 256 * 8;
-    static constexpr int LDS = OFF_MISC + 32;        // 4 wave maxima, the queue's hand-over slot
+    static constexpr int OFF_G = OFF_MISC + 32;      // 4 wave maxima, the queue's hand-over slot; then the correction band G (freq_xlating)
+    static constexpr int LDS = OFF_G + mf::NG * 64 * 16;
     static_assert((1 << LOGQ) == Q, "segment stride must be a power of two");
     static_assert(HALO >= 0 && HALO % 32 == 0, "halo");
     static_assert(mf::plane_pos(mf::WAVE_NEW * D - 1, D) + 2 - mf::plane_pos(HALO, D) >= SCR_WAVE * 4, "a wave's own stretch of a plane must hold one accumulator tile");
@@ -180,9 +182,10 @@ struct AtanPairs {
 
 }  // namespace
 
-template <int D, int KS, bool PREMIX, int EPI>
+template <int D, int KS, bool PREMIX, int EPI, bool TAPQ = false>
 __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaArgs a)
 {
+    static_assert(!TAPQ || PREMIX, "the tap-angle correction belongs to freq_xlating's pre-mix form");
     using G = Geo<D, KS>;
     constexpr int NI = G::NI, PL = G::PL, LOGQ = G::LOGQ, CB = G::CB, SP = G::SP;
     constexpr bool DEMOD = EPI == EPI_DEMOD;
@@ -210,6 +213,16 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
             Al[js] = Ag[(js * 2 + 1) * 64 + lane];
         }
     }
+    // freq_xlating: the correction band of the reference's tap-angle quantisation (mfma_tables.h), high halves of the
+    // middle k-steps, behind A in the table; its sum T joins the accumulator with the factor j: re -= T(im), im += T(re)
+    constexpr int JG0 = mf::g_first(KS);
+    // (in LDS, 4 KB, read at lane * 16 when a middle k-step comes up: in registers it would be 16 more than the 256 there are)
+    const h16x8 *Gl = reinterpret_cast<const h16x8 *>(smem + G::OFF_G) + lane;
+    if (TAPQ) {
+        const h16x8 *Gg = reinterpret_cast<const h16x8 *>(a.A) + (size_t)KS * 2 * 64;
+        if (t < mf::NG * 64) reinterpret_cast<h16x8 *>(smem + G::OFF_G)[t] = Gg[t];
+    }
+    const float tq_sgn = __builtin_amdgcn_ldexpf((lane & 8) ? 1.0f : -1.0f, -mf::G_EXTRA_EXP);
     // pre-mix phasors of the lane's two samples of round 0: e^{jw(2t - off)}, e^{jw(2t + 1 - off)}
     f32x2 wl{1.f, 0.f}, wl1{1.f, 0.f};
     if (PREMIX) {
@@ -514,16 +527,31 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
 #else
             acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
+            f32x4 tq{0.f, 0.f, 0.f, 0.f};
             // The k-steps of a block are taken from the band's ends towards its middle (0, KS-1, 1, KS-2, ...): a low-pass
             // has its large taps in the middle, so the partial sum stays small until the last two or three k-steps and
             // only those accumulations round at the output's magnitude (in index order every accumulation from the
             // middle on does).  Same MFMAs, same registers; the FAST demodulator's largest per-element deviation from
             // the reference on cfg2: 2.40e-5 in index order (round 3).
             auto kstep = [](int q) constexpr { return GRHIP_LG_ORDER ? ((q & 1) ? KS - 1 - (q >> 1) : (q >> 1)) : q; };
+            h16x8 Gcur{}, Gnext{};
 #pragma unroll
             for (int jq = 0; jq < KS; ++jq) {
                 const int j = kstep(jq);
                 const h16x8 Bh = Bh_n, Bl = Bl_n;
+                if (TAPQ) {
+                    // the correction band's operand of the NEXT k-step that needs one, a k-step ahead of its MFMA (read at the
+                    // point of use it cost an LDS round trip per middle k-step: 1.44 against 1.22 ms).  The address goes through
+                    // an empty asm: a plain loop-invariant LDS read is hoisted out of the tile loop, and G is back in sixteen
+                    // registers the kernel does not have.
+                    Gcur = Gnext;
+                    const int jn = jq + 1 < KS ? kstep(jq + 1) : (b + 1 < NBLK ? kstep(0) : -1);
+                    if (jn >= JG0 && jn < JG0 + mf::NG) {
+                        const h16x8 *gp = Gl + (jn - JG0) * 64;
+                        asm volatile("" : "+v"(gp));
+                        Gnext = *gp;
+                    }
+                }
                 const int cn = jq + 1 < KS ? CB * b + kstep(jq + 1) : CB * (b + 1) + kstep(0);       // next chunk: this block's, or the next block's first
                 if (jq + 1 < KS || b + 1 < NBLK) {
                     const unsigned char *src = chunk_ptr(cn);
@@ -542,11 +570,23 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[j], Bl, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[j], Bh, acc[b], 0, 0, 0);
 #endif
+                if (TAPQ && j >= JG0 && j < JG0 + mf::NG) {
+                    // the other part's chunk of the same segment sits in the lane 8 places round the row of 16 (column ^ 8)
+                    const u32x4 bw = __builtin_bit_cast(u32x4, Bh);
+                    u32x4 sw;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sw[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)bw[e], 0x128, 0xf, 0xf, false);   // row_ror:8
+                    tq = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gcur, __builtin_bit_cast(h16x8, sw), tq, 0, 0, 0);
+                }
                 if (jq == 1) fetch(rsrc_n, voff_n, b);       // a quarter of the next tile's loads per block
             }
 #if GRHIP_LG_ACC3
             acc[b] = GRHIP_LG_ACC3 == 1 ? (m0 + m1) + lo : m0 + lo;
 #endif
+            if (TAPQ) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[b][e] = __builtin_fmaf(tq_sgn, tq[e], acc[b][e]);
+            }
         }
         }
         MF_STAMP(4);
@@ -1186,11 +1226,11 @@ __global__ void __launch_bounds__(rs::THREADS, 1) fir_mfma_rs_kernel(const FirMf
 
 static int g_mf_cus = 0;
 
-template <int D, int KS, bool PREMIX, int EPI>
+template <int D, int KS, bool PREMIX, int EPI, bool TAPQ = false>
 static int launch_mfma_inst(const FirMfmaArgs &a, hipStream_t st)
 {
     using G = Geo<D, KS>;
-    auto kern = fir_mfma_kernel<D, KS, PREMIX, EPI>;
+    auto kern = fir_mfma_kernel<D, KS, PREMIX, EPI, TAPQ>;
     static bool configured = false;
     if (!configured) {
         GRHIP_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
@@ -1245,6 +1285,10 @@ template <int D, int KS>
 static int launch_mfma_dk(bool premix, int epi, const FirMfmaArgs &a, hipStream_t st)
 {
     if (premix) {
+        if (a.tapq) {
+            if (epi == EPI_DEMOD) return launch_mfma_inst<D, KS, true, EPI_DEMOD, true>(a, st);
+            if (epi == EPI_ROTATE) return launch_mfma_inst<D, KS, true, EPI_ROTATE, true>(a, st);
+        }
         if (epi == EPI_DEMOD) return launch_mfma_inst<D, KS, true, EPI_DEMOD>(a, st);
         if (epi == EPI_ROTATE) return launch_mfma_inst<D, KS, true, EPI_ROTATE>(a, st);
         return fail(GRHIP_EINVAL, "matrix FIR: the pre-mix form needs a rotate or demod epilogue");

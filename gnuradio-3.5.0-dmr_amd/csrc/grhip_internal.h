@@ -134,9 +134,9 @@ struct HandleBase {
 };
 
 int default_mode();
-inline bool mode_valid(int m) { return m == GRHIP_MODE_FAST || m == GRHIP_MODE_GENERIC || m == GRHIP_MODE_FAST_VALU; }
-inline bool mode_fast(int m) { return m != GRHIP_MODE_GENERIC; }          // FAST or FAST_VALU
-inline bool mode_matrix(int m) { return m == GRHIP_MODE_FAST; }           // matrix cores allowed
+inline bool mode_valid(int m) { return m == GRHIP_MODE_FAST || m == GRHIP_MODE_GENERIC || m == GRHIP_MODE_FAST_VALU || m == GRHIP_MODE_FAST_REFTAPS; }
+inline bool mode_fast(int m) { return m != GRHIP_MODE_GENERIC; }          // FAST, FAST_VALU or FAST_REFTAPS
+inline bool mode_matrix(int m) { return m == GRHIP_MODE_FAST || m == GRHIP_MODE_FAST_REFTAPS; }   // matrix cores allowed
 
 // shared read-only device tables (per device, created on first use)
 struct DeviceTables {

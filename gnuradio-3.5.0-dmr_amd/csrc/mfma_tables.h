@@ -125,5 +125,36 @@ inline void build_A(const float *h, int T, int D, int KS, int off, int kexp, std
             }
 }
 
+// ---- the reference's tap-angle quantisation (freq_xlating only) -----------------------------------------
+// gr_freq_xlating_fir_filter builds its composite taps as proto[i] * exp(j * (float)(i * fwT0)) with the product i * fwT0
+// rounded to binary32 (filter/gr_freq_xlating_fir_filter_XXX.cc.t:79): tap i carries an angle error e_i of up to half an
+// ulp of a number as large as ntaps * fwT0 (7.6e-6 rad at 256 taps and fwT0 = pi/4).  The pre-mix form evaluates exact
+// angles; on a signal whose phase turns through the filter's span that difference is what separates its demodulator
+// output from the reference's (1.64e-5 of 1.69e-5 per element on cfg2).  To first order
+//      h[i] e^{j e_i} = h[i] + j g[i],   g[i] = h[i] e_i,
+// so the reference's output is the real-tap sum plus j times a second real-tap sum with the taps g -- a band matrix G
+// like A, needed to ~10 bits only (high halves, one MFMA per k-step), and only for the NG middle k-steps that hold the
+// prototype's main lobe for every row of a block.
+constexpr int NG = 4;                                   // k-steps that carry the correction
+constexpr int g_first(int KS) { return KS / 2 - NG / 2; }
+constexpr int G_EXTRA_EXP = 10;                         // g is ~2^-18 of h: scaled by 2^10 more, taken out when T is added
+inline double tap_angle_error(int i, float fwT0) { return (double)((float)i * fwT0) - (double)i * (double)fwT0; }
+// layout [NG][64 lanes][8] binary16, appended to build_A's table
+inline void build_G(const float *h, int T, int D, int KS, int off, int kexp, float fwT0, std::vector<uint16_t> &out)
+{
+    const size_t base = out.size();
+    out.resize(base + (size_t)NG * 64 * 8, 0);
+    for (int q = 0; q < NG; ++q)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int js = g_first(KS) + q;
+                const int a = l & 15, k = CHUNK * js + 8 * (l >> 4) + j;
+                const int i = k - D * a - off;
+                if (i < 0 || i >= T || js < 0 || js >= KS) continue;
+                const double g = (double)h[i] * tap_angle_error(i, fwT0);
+                out[base + ((size_t)q * 64 + l) * 8 + j] = f32_to_f16((float)std::ldexp(g, kexp + G_EXTRA_EXP));
+            }
+}
+
 }  // namespace mf
 }  // namespace grhip

@@ -82,12 +82,27 @@ GRHIP_API const char *grhip_version(void);
  *                      accumulation; csrc/fir_mfma.hip)
  *   GRHIP_MODE_FAST_VALU  as FAST but never the matrix cores: f32 FMAs on the vector
  *                      pipes only (the north-star's "no MFMA" form; ~2x slower at 256 taps)
+ *   GRHIP_MODE_FAST_REFTAPS  as FAST, and freq_xlating's matrix-core engine also reproduces the
+ *                      reference's TAP-ANGLE QUANTISATION -- its composite taps are
+ *                      proto[i] * exp(j * (float)(i * fwT0)), the product rounded to binary32
+ *                      (filter/gr_freq_xlating_fir_filter_XXX.cc.t:79): up to 7.6e-6 rad per tap at 256
+ *                      taps, which FAST's exact angles do not carry -- to first order, by a second band
+ *                      matrix on the middle k-steps.  cfg2, per element of the demodulator output: 1.16e-5
+ *                      against the reference's generic build and 8.9e-6 against its SSE build (the two are
+ *                      9.9e-6 apart; FAST: 1.80e-5), at 0.86 of FAST's rate.  Shapes the matrix-core
+ *                      engine does not take run as in FAST.
  *   GRHIP_MODE_GENERIC summation order and unfused arithmetic of
  *                      gr_fir_XXX_generic (filter/gr_fir_XXX_generic.cc.t:30-79):
- *                      bit-exact against the generic reference path */
+ *                      bit-exact against the generic reference path
+ * Error bound of the matrix-core engine (FAST, FAST_REFTAPS): every staged tile of ~2000 outputs is scaled by ONE
+ * power of two taken from its largest finite sample, so |error| <= 2^-21 * sum|taps| * (largest |sample| of the
+ * tile): absolute within a tile, not relative to the local signal (a quiet stretch beside a burst keeps the
+ * infinity-norm tolerance, not a per-element one); a non-finite sample spoils the outputs whose window holds it and
+ * at most the rest of their 16-output block. */
 #define GRHIP_MODE_FAST 0
 #define GRHIP_MODE_GENERIC 1
 #define GRHIP_MODE_FAST_VALU 2
+#define GRHIP_MODE_FAST_REFTAPS 3
 GRHIP_API int grhip_set_default_mode(int mode);
 GRHIP_API int grhip_get_default_mode(void);
 

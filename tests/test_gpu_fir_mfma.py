@@ -184,7 +184,7 @@ def test_xlating_demod_chunked_and_mode_switches(gpu, po, wl):
     xin = wl.with_history(x, hist)
     blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
     pieces = [1, 15, 16, 17, 1984, 1985, 3000, 1, 7001]
-    modes = [gpu.MODE_FAST, gpu.MODE_FAST_VALU, gpu.MODE_FAST, gpu.MODE_GENERIC, gpu.MODE_FAST]
+    modes = [gpu.MODE_FAST, gpu.MODE_FAST_VALU, gpu.MODE_FAST_REFTAPS, gpu.MODE_GENERIC, gpu.MODE_FAST]
     out = []
     pos = 0
     k = 0
@@ -197,6 +197,43 @@ def test_xlating_demod_chunked_and_mode_switches(gpu, po, wl):
     got = np.concatenate(out)
     ok, worst = demod_close(got, ref, gain=c["demod_gain"])
     assert ok, worst
+
+
+def test_reference_tap_quantisation_mode(gpu, po, wl):
+    """GRHIP_MODE_FAST_REFTAPS (round 3): the matrix-core engine also carries the reference's tap-angle quantisation --
+    composite taps proto[i] * exp(j * (float)(i * fwT0)), filter/gr_freq_xlating_fir_filter_XXX.cc.t:79 -- which is 1.64e-5
+    of FAST's 1.8e-5 per-element deviation on cfg2.  With it the demodulator output sits at the reference's own
+    reproducibility level: its generic and SSE builds are 9.9e-6 apart on this capture."""
+    from conftest import demod_report
+    c = wl.CFG2
+    n = 2_000_000
+    x = wl.fsk4_capture(n, stream_id=11)
+    proto = wl.cfg2_proto_taps()
+    nout = n // c["decim"]
+    xin = wl.with_history(x, 255)
+    ref = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], x)
+    blk = gpu.xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"])
+    blk.set_mode(gpu.MODE_FAST_REFTAPS)
+    got = blk.work(nout, xin)
+    rep = demod_report(got, ref, gain=c["demod_gain"])
+    assert rep["ok"] and rep["steady_rel_inf"] <= 1e-5
+    assert rep["per_element_rel"] <= 1.3e-5, rep                 # measured 1.16e-5 (a correctly rounded FIR: 8.8e-6)
+    if po.have_ref():
+        ref_sse = po.chain_xlating_demod(c["decim"], proto, c["center_freq"], c["fs"], c["demod_gain"], x, lib="ref")
+        rs = demod_report(got, ref_sse, gain=c["demod_gain"])
+        assert rs["per_element_rel"] <= 1e-5, rs                 # measured 8.9e-6: against the build the reference runs on x86
+    blk.set_mode(gpu.MODE_FAST)
+    fast = demod_report(blk.work(nout, xin), ref, gain=c["demod_gain"])
+    assert rep["per_element_rel"] < 0.8 * fast["per_element_rel"]
+    # the stand-alone xlating output (rotate epilogue): closer to the reference's than FAST's too
+    xl = gpu.freq_xlating_fir_filter_ccc(c["decim"], proto, c["center_freq"], c["fs"])
+    yref = po.Xlating(c["decim"], proto, c["center_freq"], c["fs"]).work(xin, nout)
+    xl.set_mode(gpu.MODE_FAST)
+    e_fast = np.abs(xl.work(nout, xin) - yref).max()
+    xl2 = gpu.freq_xlating_fir_filter_ccc(c["decim"], proto, c["center_freq"], c["fs"])
+    xl2.set_mode(gpu.MODE_FAST_REFTAPS)
+    e_ref = np.abs(xl2.work(nout, xin) - yref).max()
+    assert e_ref < 0.5 * e_fast and e_ref <= 1e-5 * np.abs(yref).max()
 
 
 def test_run_captures_matches_single_stream(gpu, po, wl):

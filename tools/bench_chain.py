@@ -69,6 +69,6 @@ print(json.dumps({"workload": "full DMR chain (xlating+demod -> M&M -> slicer+co
                   "ntaps": len(proto), "samples_per_stream": n, "ms_per_batch": ms, "Msamples_per_s": S * n / ms / 1e3,
                   "captures": "distinct stream ids 1000 ... %d" % (999 + S),
                   "symbols_min_max": [int(d_n.min().item()), int(d_n.max().item())],
-                  "access_code_flags": int(((d_bits >> 1) & 1).sum(dtype=torch.int64).item())}))
+                  "access_code_flags": int(torch.count_nonzero(d_bits & 2).item())}))
 del ch        # (streams and events released before the interpreter tears the runtime down)
 torch.cuda.synchronize()
