@@ -377,7 +377,7 @@ def chain_bench(torch, g, wl, dev, proto, n, want_caps, reps=3):
     out["binary"] = timed(d_bits, nout)
     # ---- check ----
     nb = d_n.cpu().numpy()
-    flags_dev = int(torch.count_nonzero(d_bits & 2).item())
+    flags_dev = sum(int(torch.count_nonzero(d_bits[r0:r0 + 64] & 2).item()) for r0 in range(0, d_bits.shape[0], 64))
     n_syms_nominal = nout / c4["omega"]
     planted = len(range(100, int(n_syms_nominal) - 48, c4["sync_period_syms"]))
     chk = {"access_code_flags_on_device": flags_dev, "sync_words_planted": planted * S,
@@ -543,6 +543,7 @@ def main():
     # the same step on the vector-FMA engine (the north star's "no MFMA" form), reported beside the headline: a few
     # untimed steps for the clocks, then the same K steps under HIP events
     valu_ms = None
+    reftaps_ms = None
     if a.engine == "fast" and not a.per_capture_launch:
         blk.set_mode(g.MODE_FAST_VALU)
         for _ in range(max(a.warmup, 3)):
@@ -556,6 +557,19 @@ def main():
         ev3.record(stream)
         torch.cuda.synchronize()
         valu_ms = ev2.elapsed_time(ev3) / a.steps
+        # ... and on GRHIP_MODE_FAST_REFTAPS (the matrix-core engine + the reference's tap-angle quantisation)
+        blk.set_mode(g.MODE_FAST_REFTAPS)
+        for _ in range(max(a.warmup, 3)):
+            step()
+        torch.cuda.synchronize()
+        ev4 = torch.cuda.Event(enable_timing=True)
+        ev5 = torch.cuda.Event(enable_timing=True)
+        ev4.record(stream)
+        for _ in range(a.steps):
+            step()
+        ev5.record(stream)
+        torch.cuda.synchronize()
+        reftaps_ms = ev4.elapsed_time(ev5) / a.steps
         blk.set_mode(g.MODE_FAST)
 
     if rank == 0:
@@ -602,6 +616,14 @@ def main():
                                     "kernel": "fir_tiled_kernel<D=4,premix,demod>", "kernel_ms": valu_ms,
                                     "Msamples_per_s_per_gpu": B * n / valu_ms / 1e3,
                                     "frac": alg_bytes / (valu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if reftaps_ms is not None:
+            res["reference_taps_engine"] = {
+                "engine": "GRHIP_MODE_FAST_REFTAPS (matrix-core engine + the reference's tap-angle quantisation: demodulator per "
+                          "element 1.16e-5 against the reference's generic build, 8.9e-6 against its SSE build; FAST 1.80e-5), "
+                          "same step, rank 0",
+                "kernel": "fir_mfma_kernel<D=4,KS=10,premix,demod,tapq>", "kernel_ms": reftaps_ms,
+                "Msamples_per_s_per_gpu": B * n / reftaps_ms / 1e3,
+                "frac": alg_bytes / (reftaps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, x0_host[: a.cpu_samples], proto)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]

@@ -36,7 +36,8 @@ int default_mode()
     if (m >= 0) return m;
     const char *e = getenv("GRHIP_MODE");
     m = (e && (!strcmp(e, "generic") || !strcmp(e, "1"))) ? GRHIP_MODE_GENERIC
-        : (e && (!strcmp(e, "fast_valu") || !strcmp(e, "2"))) ? GRHIP_MODE_FAST_VALU : GRHIP_MODE_FAST;
+        : (e && (!strcmp(e, "fast_valu") || !strcmp(e, "2"))) ? GRHIP_MODE_FAST_VALU
+        : (e && (!strcmp(e, "fast_reftaps") || !strcmp(e, "3"))) ? GRHIP_MODE_FAST_REFTAPS : GRHIP_MODE_FAST;
     g_mode.store(m);
     return m;
 }

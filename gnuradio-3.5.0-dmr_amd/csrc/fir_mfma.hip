@@ -52,6 +52,9 @@
 #ifndef GRHIP_LG_ORDER
 #define GRHIP_LG_ORDER 1
 #endif
+#ifndef GRHIP_LG_SPREAD
+#define GRHIP_LG_SPREAD 0
+#endif
 
 
 namespace grhip {
@@ -279,6 +282,12 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         }
     };
 
+    auto fetch_one = [&](__amdgpu_buffer_rsrc_t rsrc, int voff, int i) __attribute__((always_inline)) {
+        int vo = voff + i * (16 * mf::THREADS);
+        if ((i + 1) * mf::ROUND > SP && 2 * t + i * mf::ROUND >= SP) vo = 0x7ffff000;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
+        pf[i] = __builtin_bit_cast(f32x4, v);
+    };
     const unsigned total_tiles = (unsigned)tiles_per_stream * (unsigned)a.n_streams;
     const unsigned Gd = gridDim.x;
     unsigned cur = blockIdx.x, nxt = cur + Gd;
@@ -547,9 +556,11 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                     Gcur = Gnext;
                     const int jn = jq + 1 < KS ? kstep(jq + 1) : (b + 1 < NBLK ? kstep(0) : -1);
                     if (jn >= JG0 && jn < JG0 + mf::NG) {
-                        const h16x8 *gp = Gl + (jn - JG0) * 64;
-                        asm volatile("" : "+v"(gp));
-                        Gnext = *gp;
+                        // (an LDS OFFSET goes through the asm and comes back as an LDS pointer: a laundered generic pointer
+                        // is read with flat_load, whose wait is vmcnt(0) -- it drained the tile prefetch: 1.38 against 1.21 ms)
+                        unsigned goff = (unsigned)(G::OFF_G + 16 * lane + (jn - JG0) * 1024);
+                        asm volatile("" : "+v"(goff));
+                        Gnext = *reinterpret_cast<const __attribute__((address_space(3))) h16x8 *>(goff);
                     }
                 }
                 const int cn = jq + 1 < KS ? CB * b + kstep(jq + 1) : CB * (b + 1) + kstep(0);       // next chunk: this block's, or the next block's first
@@ -575,10 +586,19 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                     const u32x4 bw = __builtin_bit_cast(u32x4, Bh);
                     u32x4 sw;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) sw[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)bw[e], 0x128, 0xf, 0xf, false);   // row_ror:8
+                    for (int e = 0; e < 4; ++e)          // row_ror:8 (every lane has a source: `old` is never used, and naming the source saves a move of zero)
+                        sw[e] = (unsigned)__builtin_amdgcn_update_dpp((int)bw[e], (int)bw[e], 0x128, 0xf, 0xf, false);
                     tq = __builtin_amdgcn_mfma_f32_16x16x32_f16(Gcur, __builtin_bit_cast(h16x8, sw), tq, 0, 0, 0);
                 }
+#if GRHIP_LG_SPREAD
+                {   // one of the next tile's loads behind every second k-step (instead of a quarter of them per block)
+                    constexpr int STEP = (NBLK * KS) / NI > 0 ? (NBLK * KS) / NI : 1;
+                    const int pos = b * KS + jq;
+                    if (pos % STEP == 0 && pos / STEP < NI) fetch_one(rsrc_n, voff_n, pos / STEP);
+                }
+#else
                 if (jq == 1) fetch(rsrc_n, voff_n, b);       // a quarter of the next tile's loads per block
+#endif
             }
 #if GRHIP_LG_ACC3
             acc[b] = GRHIP_LG_ACC3 == 1 ? (m0 + m1) + lo : m0 + lo;

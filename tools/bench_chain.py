@@ -69,6 +69,6 @@ print(json.dumps({"workload": "full DMR chain (xlating+demod -> M&M -> slicer+co
                   "ntaps": len(proto), "samples_per_stream": n, "ms_per_batch": ms, "Msamples_per_s": S * n / ms / 1e3,
                   "captures": "distinct stream ids 1000 ... %d" % (999 + S),
                   "symbols_min_max": [int(d_n.min().item()), int(d_n.max().item())],
-                  "access_code_flags": int(torch.count_nonzero(d_bits & 2).item())}))
+                  "access_code_flags": sum(int(torch.count_nonzero(d_bits[r0:r0 + 64] & 2).item()) for r0 in range(0, d_bits.shape[0], 64))}))
 del ch        # (streams and events released before the interpreter tears the runtime down)
 torch.cuda.synchronize()

@@ -87,8 +87,8 @@ def main():
     if po.have_ref():
         rows["reference SSE build (oracle/_ref)"] = po.chain_xlating_demod(D, proto, c["center_freq"], c["fs"], gain, x, lib="ref")
     xin = wl.with_history(x, len(proto) - 1)
-    for name, mode in (("GPU FAST (matrix cores)", g.MODE_FAST), ("GPU FAST_VALU (f32 vector)", g.MODE_FAST_VALU),
-                       ("GPU GENERIC (bit-exact order)", g.MODE_GENERIC)):
+    for name, mode in (("GPU FAST (matrix cores)", g.MODE_FAST), ("GPU FAST_REFTAPS (+ tap-angle quantisation)", g.MODE_FAST_REFTAPS),
+                       ("GPU FAST_VALU (f32 vector)", g.MODE_FAST_VALU), ("GPU GENERIC (bit-exact order)", g.MODE_GENERIC)):
         blk = g.xlating_demod(D, proto, c["center_freq"], c["fs"], gain)
         blk.set_mode(mode)
         rows[name] = blk.work(nout, xin)
@@ -102,16 +102,16 @@ def main():
             rows[name] = blk.work(nout, xin)
     print("cfg2, %d samples; per element over |ref| > 0.1 max: max / rms / samples on the arctangent step" % n)
     for k, v in rows.items():
-        print("  %-36s vs float64 yardstick: %.3e / %.3e / %d" % ((k,) + rel_figs(v, d64, gain)))
+        print("  %-44s vs float64 yardstick: %.3e / %.3e / %d" % ((k,) + rel_figs(v, d64, gain)))
     ref_g = rows["reference generic order (oracle)"]
     for k, v in rows.items():
         if v is not ref_g:
-            print("  %-36s vs reference generic:  %.3e / %.3e / %d" % ((k,) + rel_figs(v, ref_g, gain)))
+            print("  %-44s vs reference generic:  %.3e / %.3e / %d" % ((k,) + rel_figs(v, ref_g, gain)))
     if "reference SSE build (oracle/_ref)" in rows:
         ref_s = rows["reference SSE build (oracle/_ref)"]
         for k, v in rows.items():
             if k.startswith("GPU"):
-                print("  %-36s vs reference SSE:      %.3e / %.3e / %d" % ((k,) + rel_figs(v, ref_s, gain)))
+                print("  %-44s vs reference SSE:      %.3e / %.3e / %d" % ((k,) + rel_figs(v, ref_s, gain)))
 
 
 if __name__ == "__main__":

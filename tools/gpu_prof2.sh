@@ -17,6 +17,7 @@ cd $O
 MATCH="$MATCH" python3 - <<'PY'
 import csv, glob, collections, json, os
 M = os.environ["MATCH"]
+EXCL = os.environ.get("EXCLUDE", ", true>(")      # e.g. ", true>(": the GRHIP_MODE_FAST_REFTAPS instantiation that the bench line also times
 out = {}
 for f in glob.glob("trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
@@ -25,14 +26,14 @@ for f in glob.glob("trace/**/*kernel_stats.csv", recursive=True):
         for r in rows:
             w.writerow([r["Name"][:140], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
     for r in rows:
-        if M in r["Name"]:
+        if M in r["Name"] and EXCL not in r["Name"]:
             out["kernel"] = r["Name"][:120]; out["avg_ns"] = float(r["AverageNs"]); out["min_ns"] = float(r["MinNs"]); out["calls"] = int(r["Calls"])
 pm = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_mfma"):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(float); cnt = collections.Counter()
         for r in csv.DictReader(open(f)):
-            if M in r["Kernel_Name"]:
+            if M in r["Kernel_Name"] and EXCL not in r["Kernel_Name"]:
                 acc[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
         for c, v in acc.items():
             pm[c] = v / cnt[c]
