@@ -89,7 +89,7 @@ GRHIP_API const char *grhip_version(void);
  *                      taps, which FAST's exact angles do not carry -- to first order, by a second band
  *                      matrix on the middle k-steps.  cfg2, per element of the demodulator output: 1.16e-5
  *                      against the reference's generic build and 8.9e-6 against its SSE build (the two are
- *                      9.9e-6 apart; FAST: 1.80e-5), at 0.86 of FAST's rate.  Shapes the matrix-core
+ *                      9.9e-6 apart; FAST: 1.80e-5), at 0.92 of FAST's rate.  Shapes the matrix-core
  *                      engine does not take run as in FAST.
  *   GRHIP_MODE_GENERIC summation order and unfused arithmetic of
  *                      gr_fir_XXX_generic (filter/gr_fir_XXX_generic.cc.t:30-79):
