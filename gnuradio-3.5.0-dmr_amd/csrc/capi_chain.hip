@@ -56,18 +56,56 @@ struct grhip_dmr_chain : HandleBase {
 #ifndef GRHIP_MM_CUS
 #define GRHIP_MM_CUS 64
 #endif
+    // Thirty-two captures per wave (mm_pairs_kernel, the FIFO in registers): 2048 captures are 64 waves, one per SIMD of
+    // 16 CUs -- the loop's share is then the SIMDs its waves fill, rounded up to whole CUs per XCD.
+#ifndef GRHIP_MM_BIG_FORM
+#define GRHIP_MM_BIG_FORM 8           // the form from GRHIP_MM_ROWS_MIN captures on: 8 or 32 captures per wave
+#endif
     hipStream_t st_mm8 = nullptr, st_fir8 = nullptr;
-    int fir8_cus = 0;
-    int captures_per_wave = 0;        // 0: by batch size; 1 / 8: forced (grhip_dmr_chain_set_captures_per_wave)
+    int fir8_cus = 0, mm8_cus = 0, ncu = 0;
+    int captures_per_wave = 0;        // 0: by batch size; 1 / 8 / 32: forced (grhip_dmr_chain_set_captures_per_wave)
     size_t max_symbols = 0;           // 0: none (grhip_dmr_chain_set_max_symbols)
-    bool mm_rows() const { return captures_per_wave ? captures_per_wave == 8 : S >= GRHIP_MM_ROWS_MIN; }
+    int mm_form() const { return captures_per_wave ? captures_per_wave : (S >= GRHIP_MM_ROWS_MIN ? GRHIP_MM_BIG_FORM : 1); }
+    int mm_cus_wanted() const
+    {
+        if (mm_form() != 32) return GRHIP_MM_CUS;
+        const int waves = (S + 31) / 32;
+        return std::max(8, ((waves + 3) / 4 + 7) / 8 * 8);
+    }
+    // the two masked streams for a loop on `cus` CUs and the FIR on the others (made again when the share changes)
+    void ensure_masks(int cus)
+    {
+        if (cus == mm8_cus && st_mm8 && st_fir8) return;
+        if (st_mm8) (void)hipStreamDestroy(st_mm8);
+        if (st_fir8) (void)hipStreamDestroy(st_fir8);
+        st_mm8 = st_fir8 = nullptr; mm8_cus = fir8_cus = 0;
+        if (cus <= 0 || ncu < 4 * cus || ncu > 1024) return;
+        uint32_t m_mm[32] = {}, m_fir[32] = {};
+        for (int i = 0; i < ncu; ++i) (i < cus ? m_mm : m_fir)[i / 32] |= 1u << (i % 32);
+        const uint32_t words = (uint32_t)((ncu + 31) / 32);
+        if (hipExtStreamCreateWithCUMask(&st_mm8, words, m_mm) != hipSuccess) st_mm8 = nullptr;
+        if (st_mm8 && hipExtStreamCreateWithCUMask(&st_fir8, words, m_fir) != hipSuccess) st_fir8 = nullptr;
+        if (st_mm8 && !st_fir8) { (void)hipStreamDestroy(st_mm8); st_mm8 = nullptr; }
+        if (st_fir8) { fir8_cus = ncu - cus; mm8_cus = cus; }
+        (void)hipGetLastError();
+    }
     static constexpr int PIPE_CHUNKS = GRHIP_PIPE_CHUNKS;
     // 4FSK tail (grhip_dmr_chain_set_four_level): pager_slicer_fb -> unpack_k_bits(2) in front of the correlator
     bool four_level = false;
     float pager_alpha = 0.f;
     DevBuf d_sym, d_dibits, d_avg, d_nbits2;
-    hipStream_t st2 = nullptr;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_fir[PIPE_CHUNKS] = {};
+    // ... in time slices too (GRHIP_CHAIN_SLICED_TAIL=1): the four-level slicer of slice c (third stream) beside the clock
+    // recovery of slice c + 1.  It reads the symbol totals slice c left, so every slice's totals are kept (d_cnt_hist; the
+    // loop of slice c + 1 writes its own), and carries its position per capture (d_pos).  Built, bit-exact, and OFF: the
+    // slicer is one wave per capture that issues on every cycle it gets, and 2048 of them per slice beside the FIR take a
+    // third of the issue slots of the CUs they land on -- the FIR's static tile split then waits for its slowest CU:
+    // 2048 captures 91.7 ms against 54.7 with the slicer behind the last slice (profiles/r03_notes.md).
+#ifndef GRHIP_CHAIN_SLICED_TAIL
+#define GRHIP_CHAIN_SLICED_TAIL 0
+#endif
+    DevBuf d_cnt_hist, d_pos;
+    hipStream_t st2 = nullptr, st3 = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_tail = nullptr, ev_fir[PIPE_CHUNKS] = {}, ev_mm[PIPE_CHUNKS] = {};
 };
 
 extern "C" {
@@ -109,24 +147,18 @@ int grhip_dmr_chain_create(grhip_dmr_chain **h, const grhip_dmr_chain_params *p,
         rc = fail(GRHIP_EINVAL, "dmr_chain needs a decimation/tap count a batched FIR engine supports");
     if (!rc) {
         hipError_t e = hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->st3, hipStreamNonBlocking);
         if (e == hipSuccess && GRHIP_MM_CUS > 0) {
-            int ncu = 0;
-            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-            if (ncu >= 4 * GRHIP_MM_CUS && ncu <= 1024) {
-                uint32_t m_mm[32] = {}, m_fir[32] = {};
-                for (int i = 0; i < ncu; ++i) (i < GRHIP_MM_CUS ? m_mm : m_fir)[i / 32] |= 1u << (i % 32);
-                const uint32_t words = (uint32_t)((ncu + 31) / 32);
-                if (hipExtStreamCreateWithCUMask(&c->st_mm8, words, m_mm) != hipSuccess) c->st_mm8 = nullptr;
-                if (c->st_mm8 && hipExtStreamCreateWithCUMask(&c->st_fir8, words, m_fir) != hipSuccess) c->st_fir8 = nullptr;
-                if (c->st_mm8 && !c->st_fir8) { (void)hipStreamDestroy(c->st_mm8); c->st_mm8 = nullptr; }
-                if (c->st_fir8) c->fir8_cus = ncu - GRHIP_MM_CUS;
-                (void)hipGetLastError();
-            }
+            (void)hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device);
+            c->ensure_masks(c->mm_cus_wanted());
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_begin, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_end, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming);
         for (int i = 0; i < grhip_dmr_chain::PIPE_CHUNKS && e == hipSuccess; ++i)
             e = hipEventCreateWithFlags(&c->ev_fir[i], hipEventDisableTiming);
+        for (int i = 0; i < grhip_dmr_chain::PIPE_CHUNKS && e == hipSuccess; ++i)
+            e = hipEventCreateWithFlags(&c->ev_mm[i], hipEventDisableTiming);
         if (e != hipSuccess) rc = fail(GRHIP_ERUNTIME, "stream / event creation: %s", hipGetErrorString(e));
     }
     size_t S = (size_t)n_streams;
@@ -135,6 +167,7 @@ int grhip_dmr_chain_create(grhip_dmr_chain **h, const grhip_dmr_chain_params *p,
     if (!rc) rc = c->d_mm.reserve(S * sizeof(MMState));
     if (!rc) rc = c->d_mm_init.reserve(S * sizeof(MMState));
     if (!rc) rc = c->d_counts.reserve(S * 2 * sizeof(int));
+    if (!rc) rc = c->d_cnt_hist.reserve((size_t)grhip_dmr_chain::PIPE_CHUNKS * S * 2 * sizeof(int));
     if (!rc) rc = c->d_ystate.reserve(S * 2 * sizeof(float2));
     if (!rc) rc = c->d_corr.reserve(S * sizeof(CorrState));
     if (!rc) {
@@ -155,7 +188,11 @@ void grhip_dmr_chain_destroy(grhip_dmr_chain *h)
     h->d_demod.release(); h->d_soft.release(); h->d_mm.release(); h->d_mm_init.release();
     h->d_counts.release(); h->d_ystate.release(); h->d_corr.release(); h->d_scratch.release();
     h->d_sym.release(); h->d_dibits.release(); h->d_avg.release(); h->d_nbits2.release();
+    h->d_cnt_hist.release(); h->d_pos.release();
     if (h->st2) (void)hipStreamDestroy(h->st2);
+    if (h->st3) (void)hipStreamDestroy(h->st3);
+    if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
+    for (auto &e : h->ev_mm) if (e) (void)hipEventDestroy(e);
     if (h->st_mm8) (void)hipStreamDestroy(h->st_mm8);
     if (h->st_fir8) (void)hipStreamDestroy(h->st_fir8);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
@@ -191,6 +228,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
     const float2 *x = (const float2 *)d_in - hist;
     float2 *ys = h->d_ystate.as<float2>();
     hipStream_t st_mm = st;         // the stream the clock recovery and the correlator run on
+    bool sliced_tail = false;       // the four-level slicer has run beside the clock recovery, slice by slice
     if (mode_fast(h->mode)) {
         // FIR + demodulator in time slices on `st`; the clock recovery of a slice starts on the second stream as
         // soon as that slice is written and continues from where the previous slice left it (mm_kernel's resume
@@ -200,13 +238,24 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         // (up to PIPE_CHUNKS slices of at least 8192 outputs: 16 -> 32 slices +2.4 % at 2048 captures, +1 % at 1024, same box)
         const int NC = n_out >= 64 * 1024 ? (int)std::min<long long>(grhip_dmr_chain::PIPE_CHUNKS, n_out / 8192) : 1;
         const long long Lc = ((n_out + NC - 1) / NC + 63) / 64 * 64;       // slice length in outputs (rows stay 16-byte aligned)
+        const int nsl = (int)((n_out + Lc - 1) / Lc);                      // slices that hold outputs (<= NC)
         GRHIP_HIP(hipMemsetAsync(h->d_counts.p, 0, S * 2 * sizeof(int), st));
+        // the totals slice c leaves: d_cnt_hist[c] (the last slice's: d_counts, where the stages behind read them)
+        auto totals = [&](int c) { return c == nsl - 1 ? h->d_counts.as<int>() : h->d_cnt_hist.as<int>() + (size_t)c * S * 2; };
+        sliced_tail = GRHIP_CHAIN_SLICED_TAIL && h->four_level && nsl > 1;
+        if (sliced_tail) {
+            GRHIP_HIP(hipMemsetAsync(h->d_avg.p, 0, S * sizeof(float), st));                     // d_avg = 0 (pager_slicer_fb.cc:40)
+            GRHIP_HIP(hipMemsetAsync(h->d_pos.p, 0, S * sizeof(int), st));
+        }
         // (ring of 1024 samples while four waves per CU of the loop's share hold the batch, else 512: see mm_rows_kernel)
         // (without the masked streams -- their creation failed -- the loop and the FIR share every CU: the batch-size rule then
         // keeps one wave per capture; a forced 8 runs with the small ring beside a FIR held to one workgroup per CU)
+        const int form = h->mm_form();
+        if (form != 1 && h->ncu) h->ensure_masks(h->mm_cus_wanted());
         const bool masks = h->st_mm8 && h->st_fir8;
-        const bool want_rows = h->mm_rows() && (masks || h->captures_per_wave == 8);
-        const int rows = want_rows ? (masks && (h->S + 7) / 8 <= 4 * GRHIP_MM_CUS ? 1024 : 512) : 0;
+        const bool want_rows = form != 1 && (masks || h->captures_per_wave == 8);
+        // (launch_mm's `rows`: 32 = thirty-two captures per wave; else the ring of the eight-captures form)
+        const int rows = !want_rows ? 0 : form == 32 && masks ? 32 : (masks && (h->S + 7) / 8 <= 4 * GRHIP_MM_CUS ? 1024 : 512);
         // eight captures per wave: the loop and the FIR on CUs of their own (two masked streams)
         const bool split = rows && NC > 1 && masks;
         hipStream_t st_side = split ? h->st_mm8 : h->st2;
@@ -214,6 +263,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         GRHIP_HIP(hipEventRecord(h->ev_begin, st));
         GRHIP_HIP(hipStreamWaitEvent(st_side, h->ev_begin, 0));
         if (split) GRHIP_HIP(hipStreamWaitEvent(st_fir, h->ev_begin, 0));
+        if (sliced_tail) GRHIP_HIP(hipStreamWaitEvent(h->st3, h->ev_begin, 0));
         st_mm = NC > 1 ? st_side : st;
         h->core.mf_wg_cap = NC > 1 ? (split ? GRHIP_CHAIN_WGCAP_ROWS : GRHIP_CHAIN_WGCAP) : 0;
         h->core.mf_cu_cap = split ? h->fir8_cus : 0;
@@ -235,8 +285,18 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
             // 2) M&M clock recovery, one wavefront per stream, over what has been demodulated so far
             rc = launch_mm(h->d_mm.as<MMState>(), h->S, mm_nout, (int)(o0 + len), h->d_demod.as<float>(),
                            (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
-                           h->d_counts.as<int>(), h->tabs->mmse_rev, st_mm, 1, rows);
+                           c == 0 ? h->d_counts.as<int>() : totals(c - 1), h->tabs->mmse_rev, st_mm, 1, rows,
+                           nsl > 1 ? totals(c) : nullptr);
             if (rc) { h->core.mf_wg_cap = 0; h->core.mf_cu_cap = 0; return rc; }
+            if (sliced_tail) {
+                // 3') 4FSK, in slices: the symbols this slice's clock recovery has added, on the third stream
+                GRHIP_HIP(hipEventRecord(h->ev_mm[c], st_mm));
+                GRHIP_HIP(hipStreamWaitEvent(h->st3, h->ev_mm[c], 0));
+                rc = launch_pager_slicer(h->d_avg.as<float>(), h->S, h->pager_alpha, 1.0f - h->pager_alpha, h->d_soft.as<float>(),
+                                         (long long)h->out_stride, h->d_sym.as<unsigned char>(), (long long)h->out_stride, n_out,
+                                         h->st3, totals(c), 2, h->d_pos.as<int>());
+                if (rc) { h->core.mf_wg_cap = 0; h->core.mf_cu_cap = 0; return rc; }
+            }
         }
         h->core.mf_cu_cap = 0;
         if (split) {
@@ -264,7 +324,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         // 2) M&M clock recovery, one wavefront per stream
         rc = launch_mm(h->d_mm.as<MMState>(), h->S, mm_nout, (int)n_out, h->d_demod.as<float>(),
                        (long long)h->out_stride, h->d_soft.as<float>(), (long long)h->out_stride,
-                       h->d_counts.as<int>(), h->tabs->mmse_rev, st, 0, h->mm_rows() ? 512 : 0);
+                       h->d_counts.as<int>(), h->tabs->mmse_rev, st, 0, h->mm_form() == 32 ? 32 : h->mm_form() == 8 ? 512 : 0);
         if (rc) return rc;
     }
 
@@ -273,11 +333,16 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
     const long long n_expect = (long long)((double)n_out / (double)h->mm_init.omega_mid * 1.125) + 4096;
     if (h->four_level) {
         // 3') 4FSK: DC-tracking four-level slicer, dibit unpack, correlator on the bit stream (2 items per symbol)
-        GRHIP_HIP(hipMemsetAsync(h->d_avg.p, 0, S * sizeof(float), st_mm));                      // d_avg = 0 (pager_slicer_fb.cc:40)
-        rc = launch_pager_slicer(h->d_avg.as<float>(), h->S, h->pager_alpha, 1.0f - h->pager_alpha, h->d_soft.as<float>(),
-                                 (long long)h->out_stride, h->d_sym.as<unsigned char>(), (long long)h->out_stride, n_out, st_mm,
-                                 h->d_counts.as<int>(), 2);
-        if (rc) return rc;
+        if (sliced_tail) {
+            GRHIP_HIP(hipEventRecord(h->ev_tail, h->st3));
+            GRHIP_HIP(hipStreamWaitEvent(st_mm, h->ev_tail, 0));
+        } else {
+            GRHIP_HIP(hipMemsetAsync(h->d_avg.p, 0, S * sizeof(float), st_mm));                  // d_avg = 0 (pager_slicer_fb.cc:40)
+            rc = launch_pager_slicer(h->d_avg.as<float>(), h->S, h->pager_alpha, 1.0f - h->pager_alpha, h->d_soft.as<float>(),
+                                     (long long)h->out_stride, h->d_sym.as<unsigned char>(), (long long)h->out_stride, n_out, st_mm,
+                                     h->d_counts.as<int>(), 2);
+            if (rc) return rc;
+        }
         rc = launch_unpack_k_bits_streams(2, h->S, h->d_sym.as<unsigned char>(), (long long)h->out_stride,
                                           h->d_dibits.as<unsigned char>(), 2 * (long long)h->out_stride, n_out,
                                           h->d_counts.as<int>(), 2, h->d_nbits2.as<int>(), 1, st_mm);
@@ -316,7 +381,8 @@ int grhip_dmr_chain_set_mode(grhip_dmr_chain *h, int mode)
 
 int grhip_dmr_chain_set_captures_per_wave(grhip_dmr_chain *h, int captures)
 {
-    if (!h || !(captures == 0 || captures == 1 || captures == 8)) return fail(GRHIP_EINVAL, "captures per wave: 0 (by batch size), 1 or 8");
+    if (!h || !(captures == 0 || captures == 1 || captures == 8 || captures == 32))
+        return fail(GRHIP_EINVAL, "captures per wave: 0 (by batch size), 1, 8 or 32");
     h->captures_per_wave = captures;
     return GRHIP_OK;
 }
@@ -338,6 +404,7 @@ int grhip_dmr_chain_set_four_level(grhip_dmr_chain *h, int enable, float pager_a
         if ((rc = h->d_sym.reserve(S * h->out_stride))) return rc;
         if ((rc = h->d_dibits.reserve(S * 2 * h->out_stride))) return rc;
         if ((rc = h->d_avg.reserve(S * sizeof(float)))) return rc;
+        if ((rc = h->d_pos.reserve(S * sizeof(int)))) return rc;
         if ((rc = h->d_nbits2.reserve(S * sizeof(int)))) return rc;
     }
     h->four_level = enable != 0;

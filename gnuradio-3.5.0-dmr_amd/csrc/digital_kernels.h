@@ -18,16 +18,17 @@ struct MMState {
 // resume != 0: counts[] hold the stream's totals so far, the call continues from there with
 // noutput_items / ninput_items counted from the stream's start (see mm_kernel).
 // rows != 0: eight streams per wave (mm_rows_kernel; 16-byte aligned rows with 3 floats of slack behind ninput_items);
-// rows >= 1024: with the ring of 1024 samples (36 KB of LDS per wave), else 512 (20 KB).
+// rows >= 1024: with the ring of 1024 samples (36 KB of LDS per wave), else 512 (20 KB); rows == 32: thirty-two streams per
+// wave (mm_pairs_kernel).  counts_out: where the totals go instead of counts[] (counts[] is then only read).
 int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items, const float *in,
               long long in_stride, float *out, long long out_stride, int *counts,
-              const float *mmse_rev, hipStream_t st, int resume = 0, int rows = 0);
+              const float *mmse_rev, hipStream_t st, int resume = 0, int rows = 0, int *counts_out = nullptr);
 
 int launch_binary_slicer(const float *in, unsigned char *out, long long n, hipStream_t st);
 // pager_slicer_fb: d_avg[s] carried in device memory; streams s at in + s*in_stride / out + s*out_stride
 int launch_pager_slicer(float *d_avg, int n_streams, float alpha, float beta, const float *in, long long in_stride,
                         unsigned char *out, long long out_stride, long long n, hipStream_t st, const int *n_ptr = nullptr,
-                        int n_ptr_stride = 0);
+                        int n_ptr_stride = 0, int *pos = nullptr);       // pos[s]: items sliced so far, the call resumes there
 int launch_unpack_k_bits_streams(unsigned k, int n_streams, const unsigned char *in, long long in_stride, unsigned char *out,
                                  long long out_stride, long long n_in_max, const int *n_ptr, int n_ptr_stride, int *n_out,
                                  int n_out_stride, hipStream_t st);

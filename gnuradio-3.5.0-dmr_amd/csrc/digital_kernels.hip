@@ -2,6 +2,7 @@
 //   digital_clock_recovery_mm_ff (+ gri_mmse_fir_interpolator),
 //   digital_binary_slicer_fb, digital_correlate_access_code_bb.
 #include "digital_kernels.h"
+#include <type_traits>
 
 #include "device_math.h"
 #include "grhip_internal.h"
@@ -54,7 +55,7 @@ __device__ __forceinline__ float row_shl(float v)
 __global__ void __launch_bounds__(64)
 mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, const float *__restrict__ in,
           long long in_stride, float *__restrict__ out, long long out_stride, int *__restrict__ counts,
-          const float *__restrict__ mmse_rev, int resume)
+          const float *__restrict__ mmse_rev, int resume, int *__restrict__ counts_out)
 {
     __shared__ float s_in[MM_CH];
     __shared__ float s_taps[MM_NTAPS * (MM_NSTEPS + 1)];
@@ -154,8 +155,9 @@ mm_kernel(MMState *__restrict__ state, int noutput_items, int ninput_items, cons
         MMState so = st;
         so.mu = mu; so.omega = omega; so.last_sample = last;
         state[s] = so;
-        counts[2 * s + 0] = oo0 + oo;
-        counts[2 * s + 1] = ii;                // consume_each(ii)
+        int *co = counts_out ? counts_out : counts;       // (the chain keeps the totals of every time slice: a later stage reads
+        co[2 * s + 0] = oo0 + oo;                         // slice c's while slice c + 1 runs)
+        co[2 * s + 1] = ii;                    // consume_each(ii)
     }
 }
 
@@ -186,7 +188,7 @@ template <int MMR_RING>
 __global__ void __launch_bounds__(64)
 mm_rows_kernel(MMState *__restrict__ state, int n_streams, int noutput_items, int ninput_items,
                const float *__restrict__ in, long long in_stride, float *__restrict__ out, long long out_stride,
-               int *__restrict__ counts, const float *__restrict__ mmse_rev, int resume)
+               int *__restrict__ counts, const float *__restrict__ mmse_rev, int resume, int *__restrict__ counts_out)
 {
     constexpr int MMR_CHUNK = MMR_RING / 2;
     __shared__ __attribute__((aligned(16))) float s_ring[MMR_ROWS * MMR_RING];
@@ -325,31 +327,300 @@ mm_rows_kernel(MMState *__restrict__ state, int n_streams, int noutput_items, in
         MMState so = st;
         so.mu = mu; so.omega = omega; so.last_sample = last;
         state[s] = so;
-        counts[2 * s + 0] = oo;
-        counts[2 * s + 1] = ii;                       // consume_each(ii)
+        int *co = counts_out ? counts_out : counts;
+        co[2 * s + 0] = oo;
+        co[2 * s + 1] = ii;                           // consume_each(ii)
     }
 }
 
+// ---------------------------------------------------------------------------
+// mm_pairs_kernel: THIRTY-TWO captures per wavefront, two lanes each (the chain's biggest batches).
+// The loop is a latency chain -- a symbol costs what its ~50 dependent instructions and one LDS round trip cost,
+// whatever the lanes hold -- so the batch's clock recovery takes (symbols per capture) x (time per pass) however many
+// captures a wave carries, and what a design can choose is how many SIMDs and how much LDS that time occupies beside
+// the FIR.  mm_rows_kernel (8 lanes per capture: one tap product per lane, DPP sum) needs a wave per 8 captures and
+// 4 KB of ring per capture to ride out the memory latency beside a kernel that keeps HBM's queues full (several us):
+// 2048 captures = 256 waves and 9 MB of LDS = 64 CUs the FIR does not get.  Here:
+//  * lane h of a pair forms taps 4h .. 4h+3 of the interpolator from ONE 16-byte tap read and four sample reads, the
+//    pair's halves meet in one DPP quad swap per accumulator: acc_j = p_j + p_{j+4}, o = ((acc_0 + acc_1) + acc_2) +
+//    acc_3 -- the reference's order (gr_fir_fff_generic::filter, N_UNROLL = 4), every operation unfused: bit-exact;
+//    lane 0 of the pair hands o to both, which then run the recurrence redundantly;
+//  * samples: a ring of MMP_R per capture in LDS, laid out [position][capture] (a pass reads 64 different banks' worth:
+//    conflict-free whatever the captures' positions), eight mirrored rows behind the end so a symbol's reads never wrap;
+//  * the latency is ridden out in REGISTERS: a FIFO of MMP_NQ chunks of MMP_C samples per capture, requested
+//    MMP_NQ chunks ahead (448 samples = 45 symbols) with hand-issued loads and hand-counted waits (vmcnt counts in
+//    order; the compiler's bookkeeping cannot follow registers that are loaded in one trip of a loop and used many
+//    trips later).  52 KB of the wave's 128 KB of registers hold what mm_rows_kernel holds in LDS;
+//  * every capture of the wave accepts its next chunk in the same pass (the FIFO's slots are register NAMES, the same
+//    for all lanes); positions are per capture.  Captures drift apart by their symbol rates: a capture that has no room
+//    when another must accept (184 samples of slack) makes the wave start its FIFO again at every capture's own position;
+//  * outputs collect in LDS and leave as one 16-byte store per lane every eight passes (a store per pass would fill the
+//    memory counter the FIFO is counted with).
+// 2048 captures = 64 waves = one per SIMD of 16 CUs.  in / out as for mm_rows_kernel (rows 16-byte aligned, the rows of a
+// wave within 2 GB: checked by launch_mm).
+// ---------------------------------------------------------------------------
+constexpr int MMP_CAPS = 32, MMP_R = 256, MMP_C = 64, MMP_NQ = 7;
+constexpr int MMP_NL = MMP_C / 8;             // 16-byte loads per lane and chunk
+
+__global__ void __launch_bounds__(64)
+mm_pairs_kernel(MMState *__restrict__ state, int n_streams, int noutput_items, int ninput_items,
+                const float *__restrict__ in, long long in_stride, float *__restrict__ out, long long out_stride,
+                int *__restrict__ counts, const float *__restrict__ mmse_rev, int resume, int *__restrict__ counts_out)
+{
+    __shared__ __attribute__((aligned(16))) float s_ring[(MMP_R + MM_NTAPS) * MMP_CAPS];
+    __shared__ __attribute__((aligned(16))) float s_taps[(MM_NSTEPS + 1) * MM_NTAPS];      // [phase][tap]
+    __shared__ __attribute__((aligned(16))) float s_ob[MMP_CAPS * 8];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    const int lane = threadIdx.x, c = lane >> 1, h = lane & 1;
+    const int s0 = blockIdx.x * MMP_CAPS, s = s0 + c;
+    const bool valid = s < n_streams;
+    const int sc = valid ? s : n_streams - 1;
+    __builtin_amdgcn_s_setprio(3);
+    for (int i = lane; i < MM_NTAPS * (MM_NSTEPS + 1); i += 64) {
+        const int k = i / (MM_NSTEPS + 1), m = i - k * (MM_NSTEPS + 1);
+        s_taps[m * MM_NTAPS + k] = mmse_rev[i];
+    }
+    int oo = 0, ii = 0;
+    if (resume) { oo = counts[2 * sc]; ii = counts[2 * sc + 1]; }
+    const MMState st = state[sc];
+    float mu = st.mu, omega = st.omega, last = st.last_sample;          // identical in the lanes of a pair
+    const float omega_mid = st.omega_mid, gain_omega = st.gain_omega, gain_mu = st.gain_mu;
+    const float rel = st.omega_relative_limit;
+    const int ni = ninput_items - MM_NTAPS;           // .cc:113
+    int imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
+    imu = imu < 0 ? 0 : (imu > MM_NSTEPS ? MM_NSTEPS : imu);
+    bool live = valid && oo < noutput_items && ii < ni && ii >= 0;
+
+    // the wave's rows through two buffer descriptors (32-bit offsets; reads past the last row's data return zeros)
+    const int nrow = n_streams - s0 < MMP_CAPS ? n_streams - s0 : MMP_CAPS;
+    const unsigned long long xb = (unsigned long long)(in + (long long)s0 * in_stride);
+    const unsigned long long yb = (unsigned long long)(out + (long long)s0 * out_stride);
+    u32x4 rs_in, rs_out;
+    rs_in[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+    rs_in[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(xb >> 32) & 0xffffu));
+    rs_in[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)((((long long)(nrow - 1) * in_stride + ninput_items + 3) & ~3ll) * 4));
+    rs_in[3] = 0x00020000u;
+    rs_out[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)yb);
+    rs_out[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(yb >> 32) & 0xffffu));
+    rs_out[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)(((long long)(nrow - 1) * out_stride + noutput_items) * 4));
+    rs_out[3] = 0x00020000u;
+    const int rin = (int)((long long)(sc - s0) * in_stride * 4);        // this capture's row, bytes from the wave's first
+    const int rout = (int)((long long)(sc - s0) * out_stride * 4);
+
+    int lo = 0, hi = 0;                               // the ring holds samples [lo, hi) of the capture
+    int wlo = (int)0x80000000, wspan = 0;             // a symbol may start at ii with (unsigned)(ii - wlo) <= wspan
+    int q = 0;                                        // FIFO slot of the next chunk (the same for every capture)
+    // The FIFO lives in a[0 .. 32 MMP_NQ), named by hand: slot k is a[32k .. 32k+31], register 4i + t of it sample
+    // 4i + t of the lane's half chunk.  (As a C++ array the allocator gave every load the same four registers and copied
+    // them to the array's home right behind the load -- before the data had landed.  The compiler is told these registers
+    // are clobbered by every statement that touches them and has no use for accumulation registers of its own here.)
+#define MMP_CLOB "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223"
+    // lane h requests samples [pos + 32 h, pos + 32 h + 32) of its capture's chunk at pos
+    auto request = [&](auto slot, int pos) __attribute__((always_inline)) {
+        constexpr int B = 32 * decltype(slot)::value;
+        int vo = live ? rin + (pos + (MMP_C / 2) * h) * 4 : 0x7ffff000;      // (ended captures: no traffic)
+#if defined(GRHIP_DIAG) && defined(GRHIP_MMP_ABL)          // timing-only ablations (results are wrong): 1 no requests, 2 no ring writes,
+        if (GRHIP_MMP_ABL & 1) return;                          // 4 every capture reads the wave's first row (two lines per request)
+        if (GRHIP_MMP_ABL & 4) vo = live ? (pos + (MMP_C / 2) * h) * 4 : 0x7ffff000;
+#endif
+#define MMP_LD(i) asm volatile("buffer_load_dwordx4 a[%2:%3], %0, %1, 0 offen offset:%4" :: "v"(vo), "s"(rs_in), "n"(B + 4 * (i)), "n"(B + 4 * (i) + 3), "n"(16 * (i)) : MMP_CLOB)
+        MMP_LD(0); MMP_LD(1); MMP_LD(2); MMP_LD(3); MMP_LD(4); MMP_LD(5); MMP_LD(6); MMP_LD(7);
+#undef MMP_LD
+        static_assert(MMP_NL == 8, "eight loads per lane and chunk");
+    };
+    // the oldest chunk into the ring, its slot requested again MMP_NQ chunks further on
+    auto take = [&](auto slot) __attribute__((always_inline)) {
+        constexpr int B = 32 * decltype(slot)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MMP_NL * (MMP_NQ - 1)) : "memory");    // all but the younger slots have landed
+#if defined(GRHIP_DIAG) && defined(GRHIP_MMP_ABL)
+        if ((GRHIP_MMP_ABL & 2) && live) { hi += MMP_C; lo = lo > hi - MMP_R ? lo : hi - MMP_R; } else
+#endif
+        if (live) {
+            const int pb = (hi + (MMP_C / 2) * h) & (MMP_R - 1);
+            // rows pb + j, j = 0 .. 31 (128 bytes apart): two rows per instruction, 256 bytes = one unit of st64 apart
+            const unsigned w0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)&s_ring[pb * MMP_CAPS + c];
+            const unsigned w1 = w0 + 4 * MMP_CAPS;
+#define MMP_ST(j) asm volatile("ds_write2st64_b32 %0, a[%1], a[%2] offset0:%3 offset1:%4" :: "v"(((j) & 1) ? w1 : w0), "n"(B + (j)), "n"(B + (j) + 2), "n"((j) / 2), "n"((j) / 2 + 1) : "memory", MMP_CLOB)
+            MMP_ST(0); MMP_ST(1); MMP_ST(4); MMP_ST(5); MMP_ST(8); MMP_ST(9); MMP_ST(12); MMP_ST(13);
+            MMP_ST(16); MMP_ST(17); MMP_ST(20); MMP_ST(21); MMP_ST(24); MMP_ST(25); MMP_ST(28); MMP_ST(29);
+            if (pb == 0) {                                                     // rows 0..7 again behind the ring's end
+                const unsigned m0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)&s_ring[MMP_R * MMP_CAPS + c];
+                const unsigned m1 = m0 + 4 * MMP_CAPS;
+#define MMP_MR(j) asm volatile("ds_write2st64_b32 %0, a[%1], a[%2] offset0:%3 offset1:%4" :: "v"(((j) & 1) ? m1 : m0), "n"(B + (j)), "n"(B + (j) + 2), "n"((j) / 2), "n"((j) / 2 + 1) : "memory", MMP_CLOB)
+                MMP_MR(0); MMP_MR(1); MMP_MR(4); MMP_MR(5);
+#undef MMP_MR
+            }
+#undef MMP_ST
+            hi += MMP_C;
+            lo = lo > hi - MMP_R ? lo : hi - MMP_R;
+        }
+        request(slot, hi + (MMP_NQ - 1) * MMP_C);
+    };
+    auto accept = [&]() __attribute__((always_inline)) {
+        switch (q) {
+        case 0: take(std::integral_constant<int, 0>()); break;
+        case 1: take(std::integral_constant<int, 1>()); break;
+        case 2: take(std::integral_constant<int, 2>()); break;
+        case 3: take(std::integral_constant<int, 3>()); break;
+        case 4: take(std::integral_constant<int, 4>()); break;
+        case 5: take(std::integral_constant<int, 5>()); break;
+        default: take(std::integral_constant<int, 6>()); break;
+        }
+        static_assert(MMP_NQ == 7, "one case per FIFO slot");
+        q = q + 1 == MMP_NQ ? 0 : q + 1;
+    };
+    auto seed = [&]() __attribute__((always_inline)) {
+        if (live) { hi = ii & ~(MMP_C - 1); lo = hi; }
+        request(std::integral_constant<int, 0>(), hi);
+        request(std::integral_constant<int, 1>(), hi + MMP_C);
+        request(std::integral_constant<int, 2>(), hi + 2 * MMP_C);
+        request(std::integral_constant<int, 3>(), hi + 3 * MMP_C);
+        request(std::integral_constant<int, 4>(), hi + 4 * MMP_C);
+        request(std::integral_constant<int, 5>(), hi + 5 * MMP_C);
+        request(std::integral_constant<int, 6>(), hi + 6 * MMP_C);
+        q = 0;
+    };
+    // pending outputs: s_ob[capture][0..7], lane h stores symbols 4h .. 4h+3 of its capture
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float *const ob0 = (lds_float *)&s_ob[c * 8];
+    lds_float *obp = ob0;                             // behind the capture's last pending symbol
+    auto flush = [&]() __attribute__((always_inline)) {
+        const int obn = (int)(obp - ob0);
+        if (obn > 0) {
+            const f4 v = *reinterpret_cast<const __attribute__((address_space(3))) f4 *>(ob0 + 4 * h);
+            const int vo = rout + (oo + 4 * h) * 4;
+            if (obn == 8) {
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(v), "v"(vo), "s"(rs_out) : "memory");
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (4 * h + t < obn)
+                        asm volatile("buffer_store_dword %0, %1, %2, 0 offen offset:%3" :: "v"(v[t]), "v"(vo), "s"(rs_out), "n"(4 * t) : "memory");
+            }
+            oo += obn;
+            obp = ob0;
+            if (!(oo < noutput_items)) live = false;
+        }
+    };
+
+#if defined(GRHIP_DIAG) && defined(GRHIP_MMP_ABL)
+    for (int i = lane; i < (MMP_R + MM_NTAPS) * MMP_CAPS; i += 64) s_ring[i] = 0.f;
+#endif
+    if (__any(live)) seed();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // tap table written (one wave: LDS operations execute in order)
+    int group = 0;                                    // passes since the last flush (wave-uniform)
+    int K = __any(live && noutput_items - oo < 8) ? 1 : 8;
+    for (;;) {
+        // ---- between runs of passes: captures that have ended, the next chunk for all, the window of each
+        if (live && (!(ii < ni) || ii < 0)) live = false;      // .cc:113; the reference would read before its buffer at ii < 0
+        if (!__any(live)) break;
+        if (__any(live && !((unsigned)(ii - wlo) <= (unsigned)wspan))) {
+            const bool need = live && ii + MM_NTAPS > hi;
+            const bool room = !live || ii >= hi + MMP_C - MMP_R;
+            const bool lost = live && (ii < lo || ii - hi >= 2 * MMP_R);
+            if (__any(lost) || (__any(need) && !__all(room))) seed();
+            else if (__any(need)) accept();
+            const int lim = hi - MM_NTAPS < ni - 1 ? hi - MM_NTAPS : ni - 1;
+            const bool okw = lim >= lo;
+            wlo = okw ? lo : (int)0x80000000;
+            wspan = okw ? lim - lo : 0;
+            continue;
+        }
+        // ---- passes: one symbol of every running capture each, until one of them leaves its window or the group is full
+        const int budget = K - group;
+        const int lane_live = (int)__builtin_ctzll(__ballot(live));        // a capture that runs (there is one)
+        int n = 0;
+        if (live) {
+            do {
+                const int p = (ii + 4 * h) & (MMP_R - 1);
+                const float *rp = &s_ring[p * MMP_CAPS + c];
+                const f4 t = *reinterpret_cast<const f4 *>(&s_taps[imu * MM_NTAPS + 4 * h]);
+                const float p0 = __builtin_fmaf(t[0], rp[0], 0.0f);                  // (0 + tap * sample), see mm_kernel
+                const float p1 = __builtin_fmaf(t[1], rp[MMP_CAPS], 0.0f);
+                const float p2 = __builtin_fmaf(t[2], rp[2 * MMP_CAPS], 0.0f);
+                const float p3 = __builtin_fmaf(t[3], rp[3 * MMP_CAPS], 0.0f);
+                // lane 0 of the pair: acc_j = p_j + p_{j+4} (the other lane's sums are not used); written out, or hipcc pairs the
+                // sums into packed adds behind eight moves.  (s_nop: a DPP operand written by the instruction before)
+                float a0, a1, a2, a3;
+                asm("s_nop 1\n\tv_add_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                    : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+                float o = a0 + a1;
+                o = o + a2;
+                o = o + a3;
+                float obf;                            // lane 0's o to both lanes of the pair
+                asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf" : "=v"(obf) : "v"(o));
+                *obp++ = obf;                         // (both lanes: same word, same value)
+                const unsigned ou = __builtin_bit_cast(unsigned, obf), lb = __builtin_bit_cast(unsigned, last);
+                const float t1 = __builtin_bit_cast(float, ou ^ (lb & 0x80000000u));     // slice(last) * o
+                const float t2 = __builtin_bit_cast(float, lb ^ (ou & 0x80000000u));     // slice(o) * last
+                const float mm_val = t1 - t2;                                     // .cc:120
+                last = obf;
+                omega = omega + gain_omega * mm_val;                              // .cc:123
+                omega = omega_mid + branchless_clip(omega - omega_mid, rel);      // .cc:124
+                mu = mu + omega + gain_mu * mm_val;                               // .cc:125
+                const float fl = __builtin_floorf(mu);
+                ii += (int)fl;                                                    // .cc:127
+                mu = mu - fl;                                                     // .cc:128
+                imu = (int)__builtin_rintf(mu * (float)MM_NSTEPS);
+                ++n;
+            } while (n < budget && __all((unsigned)(ii - wlo) <= (unsigned)wspan));
+        }
+        group += __builtin_amdgcn_readlane(n, lane_live);                 // (the passes of the run: n is 0 in ended captures' lanes)
+        if (group >= K) {
+            flush();
+            group = 0;
+            K = __any(live && noutput_items - oo < 8) ? 1 : 8;
+        }
+    }
+    flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the FIFO's last requests)
+    if (valid && h == 0) {
+        MMState so = st;
+        so.mu = mu; so.omega = omega; so.last_sample = last;
+        state[s] = so;
+        int *co = counts_out ? counts_out : counts;
+        co[2 * s + 0] = oo;
+        co[2 * s + 1] = ii;                           // consume_each(ii)
+    }
+}
+#undef MMP_CLOB
+
 int launch_mm(MMState *state, int n_streams, int noutput_items, int ninput_items, const float *in,
               long long in_stride, float *out, long long out_stride, int *counts, const float *mmse_rev,
-              hipStream_t st, int resume, int rows)
+              hipStream_t st, int resume, int rows, int *counts_out)
 {
     if (n_streams <= 0) return GRHIP_OK;
+    if (rows == MMP_CAPS) {
+        if ((((uintptr_t)in) & 15) || (in_stride & 3) || (((uintptr_t)out) & 3))
+            return fail(GRHIP_EINVAL, "clock recovery, thirty-two captures per wave: rows must be 16-byte aligned");
+        if (in_stride * 4 * MMP_CAPS >= (1ll << 31) || out_stride * 4 * MMP_CAPS >= (1ll << 31))
+            return fail(GRHIP_EINVAL, "clock recovery, thirty-two captures per wave: the rows of a wave must lie within 2 GB");
+        const dim3 grid((n_streams + MMP_CAPS - 1) / MMP_CAPS);
+        hipLaunchKernelGGL(mm_pairs_kernel, grid, dim3(64), 0, st, state, n_streams, noutput_items, ninput_items, in, in_stride,
+                           out, out_stride, counts, mmse_rev, resume, counts_out);
+        GRHIP_HIP(hipGetLastError());
+        return GRHIP_OK;
+    }
     if (rows) {
         if ((((uintptr_t)in) & 15) || (in_stride & 3))
             return fail(GRHIP_EINVAL, "clock recovery, eight captures per wave: rows must be 16-byte aligned");
         const dim3 grid((n_streams + MMR_ROWS - 1) / MMR_ROWS);
         if (rows >= 1024)
             hipLaunchKernelGGL(mm_rows_kernel<1024>, grid, dim3(64), 0, st, state, n_streams, noutput_items, ninput_items, in,
-                               in_stride, out, out_stride, counts, mmse_rev, resume);
+                               in_stride, out, out_stride, counts, mmse_rev, resume, counts_out);
         else
             hipLaunchKernelGGL(mm_rows_kernel<512>, grid, dim3(64), 0, st, state, n_streams, noutput_items, ninput_items, in,
-                               in_stride, out, out_stride, counts, mmse_rev, resume);
+                               in_stride, out, out_stride, counts, mmse_rev, resume, counts_out);
         GRHIP_HIP(hipGetLastError());
         return GRHIP_OK;
     }
     hipLaunchKernelGGL(mm_kernel, dim3(n_streams), dim3(64), 0, st, state, noutput_items, ninput_items, in,
-                       in_stride, out, out_stride, counts, mmse_rev, resume);
+                       in_stride, out, out_stride, counts, mmse_rev, resume, counts_out);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
 }
@@ -367,7 +638,7 @@ constexpr int PS_CH = 1024;
 __global__ void __launch_bounds__(64)
 pager_slicer_kernel(float *__restrict__ d_avg, float alpha, float beta, const float *__restrict__ in,
                     long long in_stride, unsigned char *__restrict__ out, long long out_stride, long long n,
-                    const int *__restrict__ n_ptr, int n_ptr_stride)
+                    const int *__restrict__ n_ptr, int n_ptr_stride, int *__restrict__ pos)
 {
     __shared__ __attribute__((aligned(16))) float s_x[PS_CH], s_t[PS_CH];
     const int s = blockIdx.x, lane = threadIdx.x;
@@ -378,7 +649,9 @@ pager_slicer_kernel(float *__restrict__ d_avg, float alpha, float beta, const fl
     const float *__restrict__ x = in + (long long)s * in_stride;
     unsigned char *__restrict__ y = out + (long long)s * out_stride;
     float avg = d_avg[s];
-    for (long long base = 0; base < n; base += PS_CH) {
+    // pos: the items of stream s sliced by earlier calls (the chain's time slices); this call goes on from there
+    const long long start = pos ? pos[s] : 0;
+    for (long long base = start; base < n; base += PS_CH) {
         const int m = (int)(n - base < PS_CH ? n - base : PS_CH);
         {   // the whole window with all of a lane's loads in flight at once (PS_CH / 64 of them)
             float v[PS_CH / 64];
@@ -437,16 +710,19 @@ pager_slicer_kernel(float *__restrict__ d_avg, float alpha, float beta, const fl
         }
         __syncthreads();
     }
-    if (lane == 0) d_avg[s] = avg;
+    if (lane == 0) {
+        d_avg[s] = avg;
+        if (pos) pos[s] = (int)(n > start ? n : start);
+    }
 }
 
 int launch_pager_slicer(float *d_avg, int n_streams, float alpha, float beta, const float *in, long long in_stride,
                         unsigned char *out, long long out_stride, long long n, hipStream_t st, const int *n_ptr,
-                        int n_ptr_stride)
+                        int n_ptr_stride, int *pos)
 {
     if (n <= 0 || n_streams <= 0) return GRHIP_OK;
     hipLaunchKernelGGL(pager_slicer_kernel, dim3(n_streams), dim3(64), 0, st, d_avg, alpha, beta, in, in_stride, out,
-                       out_stride, n, n_ptr, n_ptr_stride);
+                       out_stride, n, n_ptr, n_ptr_stride, pos);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
 }

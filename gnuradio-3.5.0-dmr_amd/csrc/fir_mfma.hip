@@ -220,7 +220,6 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
     // middle k-steps, behind A in the table; its sum T joins the accumulator with the factor j: re -= T(im), im += T(re)
     constexpr int JG0 = mf::g_first(KS);
     // (in LDS, 4 KB, read at lane * 16 when a middle k-step comes up: in registers it would be 16 more than the 256 there are)
-    const h16x8 *Gl = reinterpret_cast<const h16x8 *>(smem + G::OFF_G) + lane;
     if (TAPQ) {
         const h16x8 *Gg = reinterpret_cast<const h16x8 *>(a.A) + (size_t)KS * 2 * 64;
         if (t < mf::NG * 64) reinterpret_cast<h16x8 *>(smem + G::OFF_G)[t] = Gg[t];
@@ -282,7 +281,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
         }
     };
 
-    auto fetch_one = [&](__amdgpu_buffer_rsrc_t rsrc, int voff, int i) __attribute__((always_inline)) {
+    [[maybe_unused]] auto fetch_one = [&](__amdgpu_buffer_rsrc_t rsrc, int voff, int i) __attribute__((always_inline)) {
         int vo = voff + i * (16 * mf::THREADS);
         if ((i + 1) * mf::ROUND > SP && 2 * t + i * mf::ROUND >= SP) vo = 0x7ffff000;
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);

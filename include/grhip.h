@@ -610,9 +610,10 @@ GRHIP_API void grhip_dmr_chain_destroy(grhip_dmr_chain *h);
  * generic path, symbols and bit decisions included. */
 GRHIP_API int grhip_dmr_chain_set_mode(grhip_dmr_chain *h, int mode);
 /* Scheduling of the clock recovery (digital_clock_recovery_mm_ff.cc:116-134, a serial recurrence per capture): one
- * wavefront per capture (1), or eight captures per wavefront (8: the shape for batches of more than a thousand
- * captures, where the loop then leaves the FIR its full grid); 0 = chosen by n_streams (the default).  Results are
- * identical (both forms are bit-exact on their input). */
+ * wavefront per capture (1), eight captures per wavefront (8: the shape for batches of more than a thousand
+ * captures, where the loop then leaves the FIR its full grid), or thirty-two (32: two lanes per capture, the samples
+ * through a FIFO in registers; the loop on a sixteenth of the CUs -- measured slower per symbol, DESIGN 4.3, an option);
+ * 0 = chosen by n_streams (the default: 1 or 8).  Results are identical (every form is bit-exact on its input). */
 GRHIP_API int grhip_dmr_chain_set_captures_per_wave(grhip_dmr_chain *h, int captures);
 /* Upper bound on the symbols the clock recovery produces per capture: the noutput_items of its general_work
  * (digital_clock_recovery_mm_ff.cc:113, `oo < noutput_items`); 0 = no bound but the output rows (the default).

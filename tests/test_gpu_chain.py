@@ -192,7 +192,7 @@ def test_chain_eight_captures_per_wave(gpu, po, wl, decim, ntaps, n_out, omega):
     for mode in (gpu.MODE_FAST, gpu.MODE_GENERIC):
         ch.set_mode(mode)
         got = {}
-        for cpw in (8, 1):
+        for cpw in (8, 32, 1):
             ch.set_captures_per_wave(cpw)
             d_bits.zero_(); d_n.zero_()
             torch.cuda.synchronize()
@@ -209,7 +209,7 @@ def test_chain_eight_captures_per_wave(gpu, po, wl, decim, ntaps, n_out, omega):
                 soft = np.empty(nb[s], np.float32)
                 gpu.lib().grhip_memcpy_d2h(soft.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_soft + 4 * s * s_soft),
                                            int(nb[s]) * 4)
-                if cpw == 8:
+                if cpw != 1:
                     ref, _ = po.chain_mm(omega, c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], dem)
                     assert nb[s] == len(ref), (mode, s)
                     assert bits_equal(soft, ref), (mode, s)
@@ -219,12 +219,13 @@ def test_chain_eight_captures_per_wave(gpu, po, wl, decim, ntaps, n_out, omega):
             got[cpw] = softs
         for s in range(S):
             assert bits_equal(got[8][s][0], got[1][s][0]) and np.array_equal(got[8][s][1], got[1][s][1]), (mode, s)
+            assert bits_equal(got[32][s][0], got[1][s][0]) and np.array_equal(got[32][s][1], got[1][s][1]), (mode, s)
     # the 4FSK tail behind it (reads the symbol counts the clock recovery leaves)
     ch.set_mode(gpu.MODE_FAST)
     ch.set_four_level(True, 0.01)
     d_bits2 = torch.zeros((S, 2 * n_out), dtype=torch.uint8, device=dev)
     outs = {}
-    for cpw in (8, 1):
+    for cpw in (8, 32, 1):
         ch.set_captures_per_wave(cpw)
         d_bits2.zero_()
         torch.cuda.synchronize()
@@ -232,6 +233,73 @@ def test_chain_eight_captures_per_wave(gpu, po, wl, decim, ntaps, n_out, omega):
         st.synchronize()
         outs[cpw] = (d_n.cpu().numpy().copy(), d_bits2.cpu().numpy().copy())
     assert np.array_equal(outs[8][0], outs[1][0]) and np.array_equal(outs[8][1], outs[1][1])
+    assert np.array_equal(outs[32][0], outs[1][0]) and np.array_equal(outs[32][1], outs[1][1])
+
+
+@pytest.mark.parametrize("n_out,omega", [(70_000, 10.0), (66_000, 37.3), (40_000, 3.3)])
+def test_chain_thirty_two_captures_per_wave(gpu, po, wl, n_out, omega):
+    """the clock recovery with 32 captures per wavefront, two lanes each, its samples through a FIFO in registers
+    (mm_pairs_kernel): 37 captures = one full wave and one with five pairs in use.  The captures of a wave take their
+    chunks in the same pass, so captures whose symbol clocks differ drift apart in the ring until the wave starts its FIFO
+    again: symbol rates of 39 / 40 / 41 samples per symbol (a loop that sits on its omega limit either side), one capture
+    of noise only, one that ends early (zeros).  Bit-exact on its input against the oracle, equal to the one-capture
+    form; time-sliced (FAST) and single-slice (GENERIC) runs."""
+    import ctypes
+    torch = _torch()
+    c, c4 = wl.CFG2, wl.CFG4
+    S, n = 37, n_out * 4 + 1
+    proto = wl.cfg2_proto_taps()
+    gain = c["demod_gain"]
+    xs = []
+    for s in range(S):
+        cfg = dict(c)
+        cfg["sym_rate"] = c["fs"] / (39 + s % 3)
+        x = wl.fsk4_capture(n, stream_id=200 + s, cfg=cfg)
+        if s == 7:
+            rng = np.random.default_rng(7)
+            x = (rng.normal(0, 0.5, n) + 1j * rng.normal(0, 0.5, n)).astype(np.complex64)
+        if s == 9:
+            x[n // 3:] = 0
+        xs.append(x)
+    dev = torch.device("cuda", 0)
+    stride = n + 7
+    d_in = torch.zeros((S, stride, 2), dtype=torch.float32, device=dev)
+    for s in range(S):
+        d_in[s, :n] = torch.from_numpy(xs[s].view(np.float32).reshape(-1, 2))
+    d_bits = torch.zeros((S, n_out), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(S, dtype=torch.int32, device=dev)
+    ch = gpu.dmr_chain(4, proto, c["center_freq"], c["fs"], gain, omega, c4["gain_omega"], c4["mu"], c4["gain_mu"],
+                       c4["omega_relative_limit"], wl.access_code_string(), c4["threshold"], S, n)
+    st = torch.cuda.Stream(device=dev)
+    for mode in (gpu.MODE_FAST, gpu.MODE_GENERIC):
+        ch.set_mode(mode)
+        got = {}
+        for cpw in (32, 1):
+            ch.set_captures_per_wave(cpw)
+            d_bits.zero_(); d_n.zero_()
+            torch.cuda.synchronize()
+            ch.run_device(d_in, n, stride, d_bits, n_out, d_n, st)
+            st.synchronize()
+            nb = d_n.cpu().numpy()
+            bits = d_bits.cpu().numpy()
+            p_dem, s_dem = ch.intermediate(0)
+            p_soft, s_soft = ch.intermediate(1)
+            softs = []
+            for s in range(S):
+                soft = np.empty(nb[s], np.float32)
+                gpu.lib().grhip_memcpy_d2h(soft.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_soft + 4 * s * s_soft),
+                                           int(nb[s]) * 4)
+                if cpw == 32 and s in (0, 1, 2, 7, 9, 31, 32, 36):
+                    dem = np.empty(n_out, np.float32)
+                    gpu.lib().grhip_memcpy_d2h(dem.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p_dem + 4 * s * s_dem), n_out * 4)
+                    ref, _ = po.chain_mm(omega, c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], dem)
+                    assert nb[s] == len(ref), (mode, s)
+                    assert bits_equal(soft, ref), (mode, s)
+                softs.append((soft, bits[s, :nb[s]].copy()))
+            got[cpw] = softs
+        for s in range(S):
+            assert len(got[32][s][0]) == len(got[1][s][0]), (mode, s)
+            assert bits_equal(got[32][s][0], got[1][s][0]) and np.array_equal(got[32][s][1], got[1][s][1]), (mode, s)
 
 
 @pytest.mark.parametrize("limit", [1, 7, 8, 9, 1003, 4096, 6900])
@@ -256,7 +324,7 @@ def test_clock_recovery_stops_at_its_output_limit(gpu, po, wl, limit):
     ch.set_max_symbols(limit)
     st = torch.cuda.Stream(device=dev)
     got = {}
-    for cpw in (8, 1):
+    for cpw in (8, 32, 1):
         ch.set_captures_per_wave(cpw)
         d_bits.zero_(); d_n.zero_()
         torch.cuda.synchronize()
@@ -276,7 +344,9 @@ def test_clock_recovery_stops_at_its_output_limit(gpu, po, wl, limit):
     assert bits_equal(got[8][0][3], ref[:limit])
     for s in range(S):
         assert bits_equal(got[8][0][s], got[1][0][s]), s
+        assert bits_equal(got[32][0][s], got[1][0][s]), s
     assert np.array_equal(got[8][1], got[1][1])
+    assert np.array_equal(got[32][1], got[1][1])
 
 
 @pytest.mark.parametrize("S", [1600, 2100])
