@@ -455,7 +455,14 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
     } else {
         if (n_streams != 1 || n_lo != 0)
             return fail(GRHIP_EINVAL, "generic-order path runs one stream with explicit history");
-        // generic order (bit-exact) FIR + rotate; demod as a second kernel over y
+        // generic order (bit-exact) FIR + rotate; the demodulator in the same kernel where there is one, else as a second
+        // kernel over y
+        if (demod) {
+            rc = launch_fir_generic_demod(d_taps_generic.as<float>(), ntaps, d_in, d_demod, n_out, decim, gtab, gain, atan_tab,
+                                          y_prev, y_last, st);
+            if (rc == GRHIP_OK) { pos += n_out; return GRHIP_OK; }
+            if (rc != 1) return rc;
+        }
         float2 *y = d_y;
         if (demod) {
             rc = scratch_y.reserve((size_t)(n_out + 1) * sizeof(float2));

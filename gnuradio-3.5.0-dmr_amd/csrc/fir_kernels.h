@@ -16,6 +16,11 @@ enum FirKind { FIR_FFF = 0, FIR_CCF = 1, FIR_CCC = 2 };
 // seq: one accumulator, terms in order (gri_fir_filter_with_buffer_XXX.cc.t:75-79) instead of the unrolled order
 int launch_fir_generic(FirKind kind, const float *taps_rev, int ntaps, const void *in, void *out,
                        long long n_out, int decim, const float2 *gtab, hipStream_t st, bool seq = false);
+// gr_fir_ccc_generic + rotator (gtab) + gr_quadrature_demod_cf fused, bit-exact (decimation 1 / 2 / 4, the tiled kernels'
+// shapes, y_prev != y_last); returns 1 where there is no such kernel: the caller runs the two kernels instead
+int launch_fir_generic_demod(const float *taps_rev, int ntaps, const void *in, float *d, long long n_out, int decim,
+                             const float2 *gtab, float gain, const float *atan_tab, const float2 *y_prev, float2 *y_last,
+                             hipStream_t st);
 
 // ---- (B) tiled fast kernel (complex data) ------------------------------------
 struct FirTiledArgs {

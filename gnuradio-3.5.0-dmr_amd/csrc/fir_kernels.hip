@@ -243,7 +243,203 @@ fir_generic_tiled_kernel(const float *__restrict__ taps_rev, int ntaps, const fl
     }
 }
 
+// ---------------------------------------------------------------------------
+// (A'') the tiled form with the samples in registers (decimation 1 / 2 / 4).  In (A') every term reads its sample from LDS:
+// one 8-byte read per four packed instructions, from four SIMDs, is all the LDS pipe of a CU delivers (128 bytes per
+// cycle) -- the vector pipes wait for it half the time.  Here a lane's four outputs are NEIGHBOURS (n, n+1, n+2, n+3), and
+// x[(n + 1) D + i] = x[n D + i + D]: the sample output n+1 needs for tap i is the one output n needs for tap i + D.  So the
+// lane keeps, per polyphase row, a window of four samples in registers; a tap uses the four of its row (one per output) and
+// then replaces the oldest by ONE new read: a quarter of the LDS traffic, and that read is consumed D taps (16 D packed
+// instructions) later.  The window's registers rotate with period 4 in i / D, so the tap loop is unrolled by 4 D taps
+// and every register name is static; taps beyond ntaps are skipped by wave-uniform tests (a padding tap would add
+// +0 * x terms: wrong for -0 sums and non-finite samples).  The taps themselves are wave-uniform: scalar loads, handed to
+// the packed multiplies as their one scalar operand.  LDS rows are split by slot mod 4 (lane t's slots 4t + j, j fixed,
+// are consecutive 8-byte words: conflict-free reads).  The arithmetic is (A')'s term by term: even taps into the first
+// accumulator, odd taps into the second, in increasing i, every operation unfused.
+// ---------------------------------------------------------------------------
+// DEMOD: gr_quadrature_demod_cf (quad_demod_one: the reference's operations) in the epilogue instead of the store of y --
+// d[n] needs y[n - 1]: a lane has it for three of its four outputs, gets the fourth from its neighbour through LDS, and a
+// tile starts four outputs early (its lane 0 repeats the previous tile's last four and stores nothing), so no tile waits
+// for another; d[0] takes the block's carried sample (*y_prev), the lane that holds y[n_out - 1] leaves it in *y_last.
+struct GenericDemodArgs { float *d; float gain; const float *atan_tab; const float2 *y_prev; float2 *y_last; };
+
+// Where a block's taps come from, A/B on one box (cfg2, one 10 M-sample capture, profiles/r03_generic_ab.log): scalar loads at
+// the block's start 91.4 Gsamples/s; requested a block ahead 88.5 (the wait counter SMEM shares with LDS cannot skip a load
+// in flight, so the block's first sample wait becomes a wait for everything, and 32 more scalar registers are moved per
+// block); from LDS at a wave-uniform address 84.4 (one more LDS read per tap).
+#ifndef GRHIP_GW_TAPS_LDS
+#define GRHIP_GW_TAPS_LDS 0
+#endif
+#ifndef GRHIP_GW_TAP_PREFETCH
+#define GRHIP_GW_TAP_PREFETCH 0
+#endif
+template <int KIND, int D, bool DEMOD>
+__global__ void __launch_bounds__(GT_T)
+fir_generic_win_kernel(const float *__restrict__ taps_rev, int ntaps, const float2 *__restrict__ in, long long n_in,
+                       float2 *__restrict__ out, long long n_out, const float2 *__restrict__ gtab, const GenericDemodArgs dm)
+{
+    static_assert(KIND == FIR_CCF || KIND == FIR_CCC, "complex data");
+    constexpr int R = GT_R, UB = R * D;
+    typedef float gf2 __attribute__((ext_vector_type(2)));
+    typedef float gf4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int gu4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    const int t = threadIdx.x;
+    const int kmax = (ntaps + D - 1) / D;                             // taps per polyphase row, at most
+    const int sub_len = GT_T + (kmax + R - 1) / R + 2;                // words per (row, slot mod 4)
+    const int per_row = R * sub_len;
+    gf2 *xs = reinterpret_cast<gf2 *>(gsm);                           // [D][R][sub_len]
+    float *tp = reinterpret_cast<float *>(gsm + (size_t)D * per_row * 8 + GT_T * 8);     // (GRHIP_GW_TAPS_LDS) behind rows and s_last
+    if (GRHIP_GW_TAPS_LDS)
+        for (int i = t; i < ntaps * (KIND == FIR_CCC ? 2 : 1); i += GT_T) tp[i] = taps_rev[i];
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in), 0,
+                                                                        (int)(n_in * 8 > 0x7ffffff0ll ? 0x7ffffff0ll : n_in * 8), 0x00020000);
+    constexpr int NS = DEMOD ? GT_NT - R : GT_NT;                     // new outputs per tile
+    const long long ntiles = (n_out + NS - 1) / NS;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long n0 = tile * NS - (DEMOD ? R : 0);             // (DEMOD, first tile: outputs -4 .. -1 read zeros, unused)
+        const long long u0 = n0 * D;                                  // first sample of the tile
+        const int span = (GT_NT - 1) * D + ntaps;                     // samples the tile touches
+        __syncthreads();                                              // the previous tile's reads are done
+        for (int m = 2 * t; m < span; m += 2 * GT_T) {
+            const long long u = u0 + m;
+            // (a negative offset is beyond the range as an unsigned one: zeros)
+            const gu4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, u * 8 < 0x7ffffff0ll ? (int)(u * 8) : 0x7ffffff0, 0, 0);
+            const gf4 f = __builtin_bit_cast(gf4, v);
+            const int r0 = m % D, c0 = m / D;
+            xs[r0 * per_row + (c0 % R) * sub_len + c0 / R] = gf2{f[0], f[1]};
+            const int m1 = m + 1, r1 = m1 % D, c1 = m1 / D;
+            if (m1 < span) xs[r1 * per_row + (c1 % R) * sub_len + c1 / R] = gf2{f[2], f[3]};
+        }
+        __syncthreads();
+        gf2 acc[2][R], w[D][R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { acc[0][r] = gf2{0.f, 0.f}; acc[1][r] = gf2{0.f, 0.f}; }
+        const gf2 *base = xs + t;
+#pragma unroll
+        for (int ph = 0; ph < D; ++ph)
+#pragma unroll
+            for (int j = 0; j < R; ++j) w[ph][j] = base[ph * per_row + j * sub_len];       // slot 4 t + j of row ph
+        // one tap: its four terms, then the row's next sample (slot 4 t + k + 4, k = ib / D + kk) over the one no later tap
+        // of this row uses
+        auto tap_step = [&](int ib, int j, gf2 ctap, float rtap) __attribute__((always_inline)) {
+            const int ph = j % D, kk = j / D;
+            if (KIND == FIR_CCC) {
+                // d_taps[i] * input[i] as __mulsc3 does it for finite operands: (tr xr - ti xi, tr xi + ti xr), then acc += it.
+                // The four outputs' sixteen instructions in ONE block, producers four instructions ahead of their consumers
+                // (left to the scheduler, each sum followed its two products directly: the wave waited out the packed
+                // pipeline's latency sixteen times per tap -- SQ_WAIT_INST_ANY 43 % of the wave cycles)
+                static_assert(R == 4, "four outputs per lane");
+                const gf2 v0 = w[ph][kk % R], v1 = w[ph][(1 + kk) % R], v2 = w[ph][(2 + kk) % R], v3 = w[ph][(3 + kk) % R];
+                gf2 p0, p1, p2, p3, q0, q1, q2, q3;
+                asm("v_pk_mul_f32 %0, %12, %13 op_sel_hi:[0,1]\n\t"
+                    "v_pk_mul_f32 %4, %12, %13 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+                    "v_pk_mul_f32 %1, %12, %14 op_sel_hi:[0,1]\n\t"
+                    "v_pk_mul_f32 %5, %12, %14 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+                    "v_pk_mul_f32 %2, %12, %15 op_sel_hi:[0,1]\n\t"
+                    "v_pk_mul_f32 %6, %12, %15 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+                    "v_pk_mul_f32 %3, %12, %16 op_sel_hi:[0,1]\n\t"
+                    "v_pk_mul_f32 %7, %12, %16 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+                    "v_pk_add_f32 %0, %0, %4\n\t"
+                    "v_pk_add_f32 %1, %1, %5\n\t"
+                    "v_pk_add_f32 %2, %2, %6\n\t"
+                    "v_pk_add_f32 %3, %3, %7\n\t"
+                    "v_pk_add_f32 %8, %8, %0\n\t"
+                    "v_pk_add_f32 %9, %9, %1\n\t"
+                    "v_pk_add_f32 %10, %10, %2\n\t"
+                    "v_pk_add_f32 %11, %11, %3"
+                    : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3),
+                      "+v"(acc[j & 1][0]), "+v"(acc[j & 1][1]), "+v"(acc[j & 1][2]), "+v"(acc[j & 1][3])
+#if GRHIP_GW_TAPS_LDS
+                    : "v"(ctap), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+#else
+                    : "s"(ctap), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+#endif
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[j & 1][r] = acc[j & 1][r] + w[ph][(r + kk) % R] * gf2{rtap, rtap};
+            }
+            w[ph][kk] = base[ph * per_row + kk * sub_len + ib / UB + 1];
+        };
+        int ib = 0;
+        // whole blocks: a block's taps in one scalar load, requested a block ahead (at the block's start the wave would sit
+        // out the scalar cache's latency once per block)
+        gf2 ct[UB], cn[UB];
+        float rt[UB], rn[UB];
+        const float *tsrc = GRHIP_GW_TAPS_LDS ? tp : taps_rev;
+        auto load_taps = [&](int at, gf2 (&c)[UB], float (&r)[UB]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                if (KIND == FIR_CCC) c[j] = *reinterpret_cast<const gf2 *>(tsrc + 2 * (at + j));
+                else r[j] = tsrc[at + j];
+            }
+        };
+        if (GRHIP_GW_TAP_PREFETCH && !GRHIP_GW_TAPS_LDS) {
+            if (UB <= ntaps) load_taps(0, ct, rt);
+            for (; ib + UB <= ntaps; ib += UB) {
+                if (ib + 2 * UB <= ntaps) load_taps(ib + UB, cn, rn);
+#pragma unroll
+                for (int j = 0; j < UB; ++j) tap_step(ib, j, KIND == FIR_CCC ? ct[j] : gf2{0.f, 0.f}, KIND == FIR_CCC ? 0.f : rt[j]);
+#pragma unroll
+                for (int j = 0; j < UB; ++j) { ct[j] = cn[j]; rt[j] = rn[j]; }
+            }
+        } else {
+            for (; ib + UB <= ntaps; ib += UB) {
+                load_taps(ib, ct, rt);
+#pragma unroll
+                for (int j = 0; j < UB; ++j) tap_step(ib, j, KIND == FIR_CCC ? ct[j] : gf2{0.f, 0.f}, KIND == FIR_CCC ? 0.f : rt[j]);
+            }
+        }
+        if (ib < ntaps) {                                             // the last, partial block (wave-uniform tests)
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                if (ib + j < ntaps) {
+                    if (KIND == FIR_CCC) tap_step(ib, j, *reinterpret_cast<const gf2 *>(tsrc + 2 * (ib + j)), 0.f);
+                    else tap_step(ib, j, gf2{0.f, 0.f}, tsrc[ib + j]);
+                }
+            }
+        }
+        const long long nb = n0 + (long long)R * t;
+        if (!DEMOD) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const long long n = nb + r;
+                if (n < n_out) {
+                    const gf2 y = acc[0][r] + acc[1][r];
+                    float2 o = make_float2(y[0], y[1]);
+                    if (gtab) o = cmul_ref(o, gtab[n]);               // gr_rotator::rotate: z = in * d_phase
+                    out[n] = o;
+                }
+            }
+        } else {
+            float2 y[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const long long n = nb + r;
+                const gf2 a = acc[0][r] + acc[1][r];
+                y[r] = make_float2(a[0], a[1]);
+                if (gtab && n >= 0 && n < n_out) y[r] = cmul_ref(y[r], gtab[n]);
+            }
+            float2 *s_last = reinterpret_cast<float2 *>(gsm + (size_t)D * per_row * 8);        // [GT_T], behind the sample rows
+            s_last[t] = y[R - 1];
+            __syncthreads();
+            if (t > 0) {
+                float2 prev = s_last[t - 1];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const long long n = nb + r;
+                    if (n == 0) prev = dm.y_prev ? *dm.y_prev : make_float2(0.f, 0.f);
+                    if (n >= 0 && n < n_out) dm.d[n] = quad_demod_one(y[r], prev, dm.gain, dm.atan_tab);
+                    if (n == n_out - 1 && dm.y_last) *dm.y_last = y[r];
+                    prev = y[r];
+                }
+            }
+        }
+    }
+}
+
 static int g_gt_cus = 0;
+static const bool g_generic_no_window = getenv("GRHIP_GENERIC_NO_WINDOW") != nullptr;      // (A/B: the (A') kernel on every shape)
 template <int KIND>
 static int launch_generic_tiled(const float *taps_rev, int ntaps, const void *in, void *out, long long n_out, int decim,
                                 const float2 *gtab, hipStream_t st)
@@ -274,6 +470,30 @@ static int launch_generic_tiled(const float *taps_rev, int ntaps, const void *in
     return GRHIP_OK;
 }
 
+template <int KIND, int D, bool DEMOD = false>
+static int launch_generic_win(const float *taps_rev, int ntaps, const void *in, void *out, long long n_out, const float2 *gtab,
+                              hipStream_t st, const GenericDemodArgs dm = GenericDemodArgs{})
+{
+    const int kmax = (ntaps + D - 1) / D;
+    const size_t lds = (size_t)D * GT_R * (GT_T + (kmax + GT_R - 1) / GT_R + 2) * 8 + GT_T * 8 + (GRHIP_GW_TAPS_LDS ? (size_t)ntaps * 8 : 0);
+    static size_t cfg = 0;
+    if (lds > 64 * 1024 && lds > cfg) {
+        GRHIP_HIP(hipFuncSetAttribute((const void *)fir_generic_win_kernel<KIND, D, DEMOD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cfg = lds;
+    }
+    // one workgroup per tile (nothing is set up per workgroup: the taps are scalar loads): the dispatcher hands a CU its
+    // next tile when one is done, so a stream of a few tiles per CU -- 10 M samples are 9.5 -- does not wait for the
+    // workgroups that drew one tile more (a persistent grid of 4 per CU: 80 against 84.5 Gsamples/s on one 10 M-sample capture)
+    const long long ns = DEMOD ? GT_NT - GT_R : GT_NT;
+    const long long ntiles = (n_out + ns - 1) / ns;
+    long long grid = ntiles < (1ll << 20) ? ntiles : (1ll << 20);
+    const long long n_in = (n_out - 1) * D + ntaps;                   // what the caller guarantees readable
+    hipLaunchKernelGGL((fir_generic_win_kernel<KIND, D, DEMOD>), dim3((unsigned)grid), dim3(GT_T), lds, st, taps_rev, ntaps,
+                       (const float2 *)in, n_in, (float2 *)out, n_out, gtab, dm);
+    GRHIP_HIP(hipGetLastError());
+    return GRHIP_OK;
+}
+
 template <int KIND, bool SEQ>
 static int launch_generic_inst(const float *taps_rev, int ntaps, const void *in, void *out, long long n_out, int decim,
                                size_t sh, hipStream_t st)
@@ -285,6 +505,31 @@ static int launch_generic_inst(const float *taps_rev, int ntaps, const void *in,
                        decim, (const float2 *)nullptr);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
+}
+
+// the tiled kernels' shapes (complex data, a tile's worth of outputs, a decimation and a tap count whose tile fits LDS;
+// 16-byte loads: the stream on an 8-byte boundary is served by the range check only if it starts on a 16-byte one)
+static bool generic_tiled_ok(FirKind kind, int ntaps, const void *in, long long n_out, int decim)
+{
+    return kind != FIR_FFF && ntaps >= 8 && n_out >= 2 * GT_NT && decim >= 1 && decim <= 16 &&
+           (size_t)decim * (GT_NT + ntaps / decim + 3) * 8 + (size_t)ntaps * 8 + 64 <= 150 * 1024 && (((uintptr_t)in) & 15) == 0 &&
+           ((n_out - 1) * decim + ntaps) * 8 < 0x7ffffff0ll;
+}
+
+// gr_fir_ccc_generic + rotator + gr_quadrature_demod_cf in one kernel (bit-exact); returns 1 where the shape has no such
+// kernel (the caller then runs the FIR and the demodulator as two)
+int launch_fir_generic_demod(const float *taps_rev, int ntaps, const void *in, float *d, long long n_out, int decim,
+                             const float2 *gtab, float gain, const float *atan_tab, const float2 *y_prev, float2 *y_last,
+                             hipStream_t st)
+{
+    if (n_out <= 0) return GRHIP_OK;
+    if (g_generic_no_window || !(decim == 1 || decim == 2 || decim == 4) || !generic_tiled_ok(FIR_CCC, ntaps, in, n_out, decim) ||
+        (const void *)y_prev == (const void *)y_last)
+        return 1;
+    const GenericDemodArgs dm{d, gain, atan_tab, y_prev, y_last};
+    if (decim == 4) return launch_generic_win<FIR_CCC, 4, true>(taps_rev, ntaps, in, nullptr, n_out, gtab, st, dm);
+    if (decim == 2) return launch_generic_win<FIR_CCC, 2, true>(taps_rev, ntaps, in, nullptr, n_out, gtab, st, dm);
+    return launch_generic_win<FIR_CCC, 1, true>(taps_rev, ntaps, in, nullptr, n_out, gtab, st, dm);
 }
 
 int launch_fir_generic(FirKind kind, const float *taps_rev, int ntaps, const void *in, void *out,
@@ -304,11 +549,18 @@ int launch_fir_generic(FirKind kind, const float *taps_rev, int ntaps, const voi
     // the tiled form of the same arithmetic wherever it applies: complex data, a tile's worth of outputs, a decimation
     // and a tap count whose tile fits LDS (16-byte loads: the stream on an 8-byte boundary is served by the range check
     // only if it starts on a 16-byte one)
-    if (kind != FIR_FFF && ntaps >= 8 && n_out >= 2 * GT_NT && decim >= 1 && decim <= 16 &&
-        (size_t)decim * (GT_NT + ntaps / decim + 3) * 8 + (size_t)ntaps * 8 + 64 <= 150 * 1024 && (((uintptr_t)in) & 15) == 0 &&
-        ((n_out - 1) * decim + ntaps) * 8 < 0x7ffffff0ll) {
-        return kind == FIR_CCC ? launch_generic_tiled<FIR_CCC>(taps_rev, ntaps, in, out, n_out, decim, gtab, st)
-                               : launch_generic_tiled<FIR_CCF>(taps_rev, ntaps, in, out, n_out, decim, gtab, st);
+    if (generic_tiled_ok(kind, ntaps, in, n_out, decim)) {
+        const bool ccc = kind == FIR_CCC;
+        if (!g_generic_no_window) {
+            if (decim == 4) return ccc ? launch_generic_win<FIR_CCC, 4>(taps_rev, ntaps, in, out, n_out, gtab, st)
+                                       : launch_generic_win<FIR_CCF, 4>(taps_rev, ntaps, in, out, n_out, gtab, st);
+            if (decim == 2) return ccc ? launch_generic_win<FIR_CCC, 2>(taps_rev, ntaps, in, out, n_out, gtab, st)
+                                       : launch_generic_win<FIR_CCF, 2>(taps_rev, ntaps, in, out, n_out, gtab, st);
+            if (decim == 1) return ccc ? launch_generic_win<FIR_CCC, 1>(taps_rev, ntaps, in, out, n_out, gtab, st)
+                                       : launch_generic_win<FIR_CCF, 1>(taps_rev, ntaps, in, out, n_out, gtab, st);
+        }
+        return ccc ? launch_generic_tiled<FIR_CCC>(taps_rev, ntaps, in, out, n_out, decim, gtab, st)
+                   : launch_generic_tiled<FIR_CCF>(taps_rev, ntaps, in, out, n_out, decim, gtab, st);
     }
     dim3 grid((unsigned)((n_out + 255) / 256)), block(256);
     switch (kind) {

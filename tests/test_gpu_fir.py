@@ -44,6 +44,35 @@ def test_fir_generic_mode_bit_exact(gpu, po, kind, ntaps, decim):
 
 
 @pytest.mark.parametrize("kind", ["ccf", "ccc"])
+@pytest.mark.parametrize("decim", [1, 2, 4, 3])
+@pytest.mark.parametrize("ntaps", [8, 9, 15, 16, 17, 33, 100, 257])
+def test_fir_generic_window_kernel_shapes(gpu, po, kind, ntaps, decim):
+    """the bit-exact mode's tiled kernels (decimation 1 / 2 / 4: samples in register windows, taps in blocks of 4 D with a
+    guarded last block; 3: samples from LDS): tap counts around the block sizes, an output count that is not a multiple of the
+    tile, exact and negative zeros among samples and taps (a padding tap would turn a -0 sum into +0)"""
+    rng = np.random.default_rng(ntaps * 100 + decim)
+    n = 5003
+    nin = n * decim + ntaps - 1
+    x = _rand_c(rng, nin)
+    x[rng.integers(0, nin, 200)] = 0
+    x[rng.integers(0, nin, 200)] = np.complex64(complex(-0.0, -0.0))
+    x[1000:1000 + 2 * ntaps * decim] = np.complex64(complex(-0.0, 0.0))      # whole outputs that are sums of signed zeros
+    if kind == "ccf":
+        taps = rng.uniform(-1, 1, ntaps).astype(np.float32)
+        taps[::5] = -0.0
+        blk = gpu.fir_filter_ccf(decim, taps)
+        ref = po.fir_ccf(taps, x, n, decim)
+    else:
+        taps = _rand_c(rng, ntaps)
+        taps[::5] = np.complex64(complex(-0.0, 0.0))
+        blk = gpu.fir_filter_ccc(decim, taps)
+        ref = po.fir_ccc(taps, x, n, decim)
+    blk.set_mode(gpu.MODE_GENERIC)
+    got = blk.work(n, x)
+    assert bits_equal(got, ref)
+
+
+@pytest.mark.parametrize("kind", ["ccf", "ccc"])
 @pytest.mark.parametrize("ntaps,decim", [(1, 1), (3, 1), (64, 1), (65, 2), (256, 4), (255, 4), (256, 1), (31, 8), (40, 3),
                                          (200, 3), (1500, 1), (2049, 5), (600, 8), (700, 16), (1100, 2),
                                          (900, 4), (400, 20), (100, 5), (64, 7),
@@ -367,6 +396,32 @@ def test_fused_xlating_demod_cfg2(gpu, po, wl):
     got2 = gpu.run_sync_block(blk, x, chunk=8192)
     ok, worst = demod_close(got2, ref)
     assert ok, worst
+
+
+@pytest.mark.parametrize("decim,ntaps", [(4, 256), (2, 100), (1, 33), (4, 17)])
+def test_generic_xlating_demod_in_one_kernel(gpu, po, wl, decim, ntaps):
+    """the bit-exact mode's fused kernel (gr_fir_ccc_generic order + rotator + gr_quadrature_demod_cf, decimation 1 / 2 / 4):
+    one call, then calls of uneven sizes -- the demodulator's previous sample and the rotator's phase carried across calls,
+    sizes below two tiles (where the FIR and the demodulator run as two kernels) mixed in, tile edges (1020 new outputs per
+    tile) among the sizes -- all bit-exact against the oracle's chain"""
+    c = wl.CFG2
+    n = 200_000 * decim
+    x = wl.fsk4_capture(n, stream_id=17)
+    proto = wl.cfg2_proto_taps() if ntaps == 256 else wl.lowpass_taps(ntaps, 100e3, 10e6).astype(np.complex64)
+    nout = n // decim
+    ref = po.chain_xlating_demod(decim, proto, c["center_freq"], c["fs"], c["demod_gain"], x)
+    blk = gpu.xlating_demod(decim, proto, c["center_freq"], c["fs"], c["demod_gain"])
+    blk.set_mode(gpu.MODE_GENERIC)
+    xin = wl.with_history(x, ntaps - 1)
+    assert bits_equal(blk.work(nout, xin), ref)
+    blk.reset()
+    got, pos = [], 0
+    for m in (2048, 1020, 2040, 2041, 3061, 500, 4081, 10_000, 2049, 65_536):
+        m = min(m, nout - pos)
+        got.append(blk.work(m, xin[pos * decim: (pos + m) * decim + ntaps - 1]))
+        pos += m
+    got.append(blk.work(nout - pos, xin[pos * decim:]))
+    assert bits_equal(np.concatenate(got), ref)
 
 
 @pytest.mark.parametrize("stride_pad,n", [(0, 2_000_000), (63, 1_900_001)])

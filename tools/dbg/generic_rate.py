@@ -10,7 +10,7 @@ wl = g.workload
 c = wl.CFG2
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev)
-n = 10_000_000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 proto = wl.cfg2_proto_taps()
 x = torch.randn((n + 256, 2), device=dev)
 nout = n // 4
@@ -27,4 +27,4 @@ for mode in ("MODE_GENERIC", "MODE_FAST_VALU", "MODE_FAST"):
         blk.reset(); blk.work_device(nout, x, y, st)
     e1.record(st); st.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    print("%-15s %8.3f ms per 10 M samples = %7.1f Gsamples/s" % (mode, ms, n / ms / 1e6), flush=True)
+    print("%-15s %8.3f ms per %d M samples = %7.1f Gsamples/s" % (mode, ms, n // 1000000, n / ms / 1e6), flush=True)
