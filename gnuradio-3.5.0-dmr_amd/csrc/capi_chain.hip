@@ -308,10 +308,15 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         }
         h->core.mf_wg_cap = 0;
     } else {
-        // generic order: explicit zero history in a scratch row, one stream at a time
-        rc = h->d_scratch.reserve((size_t)(hist + (long long)n_samples) * sizeof(float2));
+        // generic order: all captures in one launch where the fused generic-order kernel takes the shape (decimation
+        // 1 / 2 / 4), else explicit zero history in a scratch row, one stream at a time
+        h->core.reset();
+        const bool batched_generic = h->core.run(GRHIP_MODE_GENERIC, x, hist + (long long)n_samples, n_out, nullptr,
+                                                 h->d_demod.as<float>(), h->gain, ys, ys + S, h->tabs->atan_tab, st, h->S,
+                                                 (long long)stream_stride_items, hist, (long long)h->out_stride) == GRHIP_OK;
+        if (!batched_generic) rc = h->d_scratch.reserve((size_t)(hist + (long long)n_samples) * sizeof(float2));
         if (rc) return rc;
-        for (size_t s = 0; s < S; ++s) {
+        for (size_t s = 0; s < S && !batched_generic; ++s) {
             GRHIP_HIP(hipMemsetAsync(h->d_scratch.p, 0, (size_t)hist * sizeof(float2), st));
             GRHIP_HIP(hipMemcpyAsync(h->d_scratch.as<float2>() + hist, (const float2 *)d_in + s * stream_stride_items,
                                      n_samples * sizeof(float2), hipMemcpyDeviceToDevice, st));

@@ -453,16 +453,16 @@ int XlatingCore::run(int mode, const float2 *d_in, long long n_in, long long n_o
             GRHIP_HIP(hipMemcpyAsync(y_last, y + (n_out - 1), sizeof(float2), hipMemcpyDeviceToDevice, st));
         }
     } else {
-        if (n_streams != 1 || n_lo != 0)
-            return fail(GRHIP_EINVAL, "generic-order path runs one stream with explicit history");
-        // generic order (bit-exact) FIR + rotate; the demodulator in the same kernel where there is one, else as a second
-        // kernel over y
+        // generic order (bit-exact) FIR + rotate; the demodulator in the same kernel where there is one (that kernel also
+        // takes several streams and synthesises a fresh capture's history), else as a second kernel over y
         if (demod) {
             rc = launch_fir_generic_demod(d_taps_generic.as<float>(), ntaps, d_in, d_demod, n_out, decim, gtab, gain, atan_tab,
-                                          y_prev, y_last, st);
+                                          y_prev, y_last, st, n_streams, x_stride, out_stride, n_lo);
             if (rc == GRHIP_OK) { pos += n_out; return GRHIP_OK; }
             if (rc != 1) return rc;
         }
+        if (n_streams != 1 || n_lo != 0)
+            return fail(GRHIP_EINVAL, "generic-order path: this shape runs one stream with explicit history");
         float2 *y = d_y;
         if (demod) {
             rc = scratch_y.reserve((size_t)(n_out + 1) * sizeof(float2));
@@ -1235,8 +1235,9 @@ int grhip_xlating_demod_run_captures_device(grhip_xlating_demod *h, int n_stream
     if (rc) return rc;
     const long long n_out = (long long)(n_samples / (size_t)h->core.decim);
     if (n_out <= 0) return GRHIP_OK;
-    if (!(mode_fast(h->mode) && (h->core.use_tiled || (mode_matrix(h->mode) && h->core.use_mfma) ||
-                                 (h->core.use_hidec && h->core.hidec_premix))))
+    // (GRHIP_MODE_GENERIC: the fused generic-order kernel takes batches at decimation 1 / 2 / 4; run() says so otherwise)
+    if (mode_fast(h->mode) && !(h->core.use_tiled || (mode_matrix(h->mode) && h->core.use_mfma) ||
+                                (h->core.use_hidec && h->core.hidec_premix)))
         return fail(GRHIP_EINVAL, "run_captures needs a batched engine (FAST mode, supported decimation)");
     if (h->core.tab_start != 0 && !h->core.demod_is_direct(h->mode, true, true))
         return fail(GRHIP_EINVAL, "handle has streamed past its cached rotator table; use a fresh handle");

@@ -262,6 +262,11 @@ fir_generic_tiled_kernel(const float *__restrict__ taps_rev, int ntaps, const fl
 // tile starts four outputs early (its lane 0 repeats the previous tile's last four and stores nothing), so no tile waits
 // for another; d[0] takes the block's carried sample (*y_prev), the lane that holds y[n_out - 1] leaves it in *y_last.
 struct GenericDemodArgs { float *d; float gain; const float *atan_tab; const float2 *y_prev; float2 *y_last; };
+// Several streams in one launch (the multi-capture entries; DEMOD only): stream s reads in + s * x_stride, its first n_lo
+// items are the zeros a fresh flowgraph's history holds (never read: the pointer may lie before the capture), its outputs
+// go to d + s * out_stride, its carried samples are y_prev[s] / y_last[s].  a_shift (0 / 1): the streams start a_shift items
+// behind a 16-byte boundary -- the staging loads stay aligned, item u of a stream is item u + a_shift of the aligned row.
+struct GenericBatch { int n_streams; long long x_stride, out_stride; int n_lo, a_shift; };
 
 // Where a block's taps come from, A/B on one box (cfg2, one 10 M-sample capture, profiles/r03_generic_ab.log): scalar loads at
 // the block's start 91.4 Gsamples/s; requested a block ahead 88.5 (the wait counter SMEM shares with LDS cannot skip a load
@@ -276,13 +281,13 @@ struct GenericDemodArgs { float *d; float gain; const float *atan_tab; const flo
 template <int KIND, int D, bool DEMOD>
 __global__ void __launch_bounds__(GT_T)
 fir_generic_win_kernel(const float *__restrict__ taps_rev, int ntaps, const float2 *__restrict__ in, long long n_in,
-                       float2 *__restrict__ out, long long n_out, const float2 *__restrict__ gtab, const GenericDemodArgs dm)
+                       float2 *__restrict__ out, long long n_out, const float2 *__restrict__ gtab, const GenericDemodArgs dm,
+                       const GenericBatch gb)
 {
     static_assert(KIND == FIR_CCF || KIND == FIR_CCC, "complex data");
     constexpr int R = GT_R, UB = R * D;
     typedef float gf2 __attribute__((ext_vector_type(2)));
     typedef float gf4 __attribute__((ext_vector_type(4)));
-    typedef unsigned int gu4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     const int t = threadIdx.x;
     const int kmax = (ntaps + D - 1) / D;                             // taps per polyphase row, at most
@@ -292,24 +297,46 @@ fir_generic_win_kernel(const float *__restrict__ taps_rev, int ntaps, const floa
     float *tp = reinterpret_cast<float *>(gsm + (size_t)D * per_row * 8 + GT_T * 8);     // (GRHIP_GW_TAPS_LDS) behind rows and s_last
     if (GRHIP_GW_TAPS_LDS)
         for (int i = t; i < ntaps * (KIND == FIR_CCC ? 2 : 1); i += GT_T) tp[i] = taps_rev[i];
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(in), 0,
-                                                                        (int)(n_in * 8 > 0x7ffffff0ll ? 0x7ffffff0ll : n_in * 8), 0x00020000);
     constexpr int NS = DEMOD ? GT_NT - R : GT_NT;                     // new outputs per tile
     const long long ntiles = (n_out + NS - 1) / NS;
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int ash = gb.a_shift;
+    const long long lim = n_in + ash;                                 // items of the aligned row that exist
+    for (long long blk = blockIdx.x; blk < ntiles * gb.n_streams; blk += gridDim.x) {
+        const long long strm = blk / ntiles, tile = blk - strm * ntiles;
+        const float2 *row = in + strm * gb.x_stride - ash;            // 16-byte aligned
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(row), 0,
+                                                                            (int)(lim * 8 > 0x7ffffff0ll ? 0x7ffffff0ll : lim * 8), 0x00020000);
         const long long n0 = tile * NS - (DEMOD ? R : 0);             // (DEMOD, first tile: outputs -4 .. -1 read zeros, unused)
         const long long u0 = n0 * D;                                  // first sample of the tile
         const int span = (GT_NT - 1) * D + ntaps;                     // samples the tile touches
         __syncthreads();                                              // the previous tile's reads are done
-        for (int m = 2 * t; m < span; m += 2 * GT_T) {
-            const long long u = u0 + m;
-            // (a negative offset is beyond the range as an unsigned one: zeros)
-            const gu4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, u * 8 < 0x7ffffff0ll ? (int)(u * 8) : 0x7ffffff0, 0, 0);
-            const gf4 f = __builtin_bit_cast(gf4, v);
-            const int r0 = m % D, c0 = m / D;
-            xs[r0 * per_row + (c0 % R) * sub_len + c0 / R] = gf2{f[0], f[1]};
-            const int m1 = m + 1, r1 = m1 % D, c1 = m1 / D;
-            if (m1 < span) xs[r1 * per_row + (c1 % R) * sub_len + c1 / R] = gf2{f[2], f[3]};
+        // aligned pairs of items of the row: e = u + a_shift, even.  Items before the row or the stream's n_lo are zeros,
+        // items behind its end too; a pair that straddles the end is read as one item
+        const long long e0 = (u0 + ash) & ~1ll;
+        for (int mm = 2 * t; mm < span + 2; mm += 2 * GT_T) {
+            const long long e = e0 + mm;
+            gf4 f{0.f, 0.f, 0.f, 0.f};
+            // (only items that exist are touched: the row's first n_lo + a_shift items may lie outside the allocation)
+            const bool i0 = e >= gb.n_lo + ash && e < lim, i1 = e + 1 >= gb.n_lo + ash && e + 1 < lim;
+            if (e * 8 < 0x7ffffff0ll - 16) {
+                if (i0 && i1) {
+                    f = __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(e * 8), 0, 0));
+                } else if (i0) {
+                    const gf2 g = __builtin_bit_cast(gf2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)(e * 8), 0, 0));
+                    f[0] = g[0]; f[1] = g[1];
+                } else if (i1) {
+                    const gf2 g = __builtin_bit_cast(gf2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)(e * 8 + 8), 0, 0));
+                    f[2] = g[0]; f[3] = g[1];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const long long u = e + q - ash;                      // the stream's item
+                const int m = (int)(u - u0);                          // its place in the tile
+                if (m >= 0 && m < span) {
+                    xs[(m % D) * per_row + ((m / D) % R) * sub_len + (m / D) / R] = gf2{f[2 * q], f[2 * q + 1]};
+                }
+            }
         }
         __syncthreads();
         gf2 acc[2][R], w[D][R];
@@ -425,12 +452,13 @@ fir_generic_win_kernel(const float *__restrict__ taps_rev, int ntaps, const floa
             __syncthreads();
             if (t > 0) {
                 float2 prev = s_last[t - 1];
+                float *dd = dm.d + strm * gb.out_stride;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const long long n = nb + r;
-                    if (n == 0) prev = dm.y_prev ? *dm.y_prev : make_float2(0.f, 0.f);
-                    if (n >= 0 && n < n_out) dm.d[n] = quad_demod_one(y[r], prev, dm.gain, dm.atan_tab);
-                    if (n == n_out - 1 && dm.y_last) *dm.y_last = y[r];
+                    if (n == 0) prev = dm.y_prev ? dm.y_prev[strm] : make_float2(0.f, 0.f);
+                    if (n >= 0 && n < n_out) dd[n] = quad_demod_one(y[r], prev, dm.gain, dm.atan_tab);
+                    if (n == n_out - 1 && dm.y_last) dm.y_last[strm] = y[r];
                     prev = y[r];
                 }
             }
@@ -472,7 +500,8 @@ static int launch_generic_tiled(const float *taps_rev, int ntaps, const void *in
 
 template <int KIND, int D, bool DEMOD = false>
 static int launch_generic_win(const float *taps_rev, int ntaps, const void *in, void *out, long long n_out, const float2 *gtab,
-                              hipStream_t st, const GenericDemodArgs dm = GenericDemodArgs{})
+                              hipStream_t st, const GenericDemodArgs dm = GenericDemodArgs{},
+                              const GenericBatch gb = GenericBatch{1, 0, 0, 0, 0}, long long n_in_arg = -1)
 {
     const int kmax = (ntaps + D - 1) / D;
     const size_t lds = (size_t)D * GT_R * (GT_T + (kmax + GT_R - 1) / GT_R + 2) * 8 + GT_T * 8 + (GRHIP_GW_TAPS_LDS ? (size_t)ntaps * 8 : 0);
@@ -485,11 +514,11 @@ static int launch_generic_win(const float *taps_rev, int ntaps, const void *in, 
     // next tile when one is done, so a stream of a few tiles per CU -- 10 M samples are 9.5 -- does not wait for the
     // workgroups that drew one tile more (a persistent grid of 4 per CU: 80 against 84.5 Gsamples/s on one 10 M-sample capture)
     const long long ns = DEMOD ? GT_NT - GT_R : GT_NT;
-    const long long ntiles = (n_out + ns - 1) / ns;
+    const long long ntiles = (n_out + ns - 1) / ns * gb.n_streams;
     long long grid = ntiles < (1ll << 20) ? ntiles : (1ll << 20);
-    const long long n_in = (n_out - 1) * D + ntaps;                   // what the caller guarantees readable
+    const long long n_in = n_in_arg >= 0 ? n_in_arg : (n_out - 1) * D + ntaps;     // what the caller guarantees readable
     hipLaunchKernelGGL((fir_generic_win_kernel<KIND, D, DEMOD>), dim3((unsigned)grid), dim3(GT_T), lds, st, taps_rev, ntaps,
-                       (const float2 *)in, n_in, (float2 *)out, n_out, gtab, dm);
+                       (const float2 *)in, n_in, (float2 *)out, n_out, gtab, dm, gb);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
 }
@@ -520,16 +549,21 @@ static bool generic_tiled_ok(FirKind kind, int ntaps, const void *in, long long 
 // kernel (the caller then runs the FIR and the demodulator as two)
 int launch_fir_generic_demod(const float *taps_rev, int ntaps, const void *in, float *d, long long n_out, int decim,
                              const float2 *gtab, float gain, const float *atan_tab, const float2 *y_prev, float2 *y_last,
-                             hipStream_t st)
+                             hipStream_t st, int n_streams, long long x_stride, long long out_stride, long long n_lo)
 {
-    if (n_out <= 0) return GRHIP_OK;
-    if (g_generic_no_window || !(decim == 1 || decim == 2 || decim == 4) || !generic_tiled_ok(FIR_CCC, ntaps, in, n_out, decim) ||
-        (const void *)y_prev == (const void *)y_last)
+    if (n_out <= 0 || n_streams <= 0) return GRHIP_OK;
+    // the aligned row every stream's items sit in: one item further back where the stream starts on an 8-byte boundary
+    const int a_shift = (((uintptr_t)in) & 15) ? 1 : 0;
+    const void *row0 = (const float2 *)in - a_shift;
+    if (g_generic_no_window || !(decim == 1 || decim == 2 || decim == 4) || !generic_tiled_ok(FIR_CCC, ntaps, row0, n_out, decim) ||
+        (y_prev && (const void *)y_prev == (const void *)y_last) || (n_streams > 1 && (x_stride & 1)) || n_lo < 0 || n_lo > 0x7fffffff)
         return 1;
     const GenericDemodArgs dm{d, gain, atan_tab, y_prev, y_last};
-    if (decim == 4) return launch_generic_win<FIR_CCC, 4, true>(taps_rev, ntaps, in, nullptr, n_out, gtab, st, dm);
-    if (decim == 2) return launch_generic_win<FIR_CCC, 2, true>(taps_rev, ntaps, in, nullptr, n_out, gtab, st, dm);
-    return launch_generic_win<FIR_CCC, 1, true>(taps_rev, ntaps, in, nullptr, n_out, gtab, st, dm);
+    const GenericBatch gb{n_streams, n_streams > 1 ? x_stride : 0, n_streams > 1 ? out_stride : 0, (int)n_lo, a_shift};
+    const long long n_in = (n_out - 1) * decim + ntaps;
+    if (decim == 4) return launch_generic_win<FIR_CCC, 4, true>(taps_rev, ntaps, in, nullptr, n_out, gtab, st, dm, gb, n_in);
+    if (decim == 2) return launch_generic_win<FIR_CCC, 2, true>(taps_rev, ntaps, in, nullptr, n_out, gtab, st, dm, gb, n_in);
+    return launch_generic_win<FIR_CCC, 1, true>(taps_rev, ntaps, in, nullptr, n_out, gtab, st, dm, gb, n_in);
 }
 
 int launch_fir_generic(FirKind kind, const float *taps_rev, int ntaps, const void *in, void *out,

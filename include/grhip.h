@@ -221,7 +221,10 @@ GRHIP_API int grhip_xlating_demod_work_device(grhip_xlating_demod *h, int noutpu
  * d_in + s*in_stride_items complex items and has NO history in front (the
  * ntaps-1 zeros a fresh flowgraph preloads are supplied by the kernel);
  * n_samples items each; output s at d_out + s*out_stride_items floats,
- * n_samples/decimation items.  Does not touch the handle's streaming state. */
+ * n_samples/decimation items.  Does not touch the handle's streaming state.
+ * FAST modes: every shape a batched engine takes.  GRHIP_MODE_GENERIC (bit-exact against the reference's generic
+ * build): decimation 1 / 2 / 4 with at least 8 taps and 2048 outputs per capture, 16-byte aligned d_in and an even
+ * in_stride_items; other shapes return GRHIP_EINVAL (run them a capture at a time through work_device). */
 GRHIP_API int grhip_xlating_demod_run_captures_device(grhip_xlating_demod *h, int n_streams,
                                                       size_t n_samples, const void *d_in,
                                                       size_t in_stride_items, void *d_out,

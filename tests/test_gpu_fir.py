@@ -457,6 +457,37 @@ def test_run_captures_batched_vs_oracle(gpu, po, wl, stride_pad, n):
             assert ok, (rep, s, worst)
 
 
+@pytest.mark.parametrize("decim,ntaps,stride_pad,n", [(4, 256, 0, 300_000), (4, 256, 62, 250_003), (2, 100, 2, 120_001),
+                                                      (1, 32, 0, 40_000), (1, 33, 4, 30_001)])
+def test_run_captures_generic_mode_bit_exact(gpu, po, wl, decim, ntaps, stride_pad, n):
+    """the multi-capture entry in the bit-exact mode: every capture of a batch through the fused generic-order kernel in one
+    launch (fresh history synthesised, never read: the captures' rows start 8 bytes off a 16-byte boundary once the history
+    is counted in when ntaps is even), each bit-exact against the oracle's chain; even strides, lengths that are no
+    multiple of the decimation"""
+    import torch
+    c = wl.CFG2
+    S = 3
+    proto = wl.cfg2_proto_taps() if ntaps == 256 else wl.lowpass_taps(ntaps, 100e3, 10e6).astype(np.complex64)
+    xs = [wl.fsk4_capture(n, stream_id=110 + s) for s in range(S)]
+    dev = torch.device("cuda", 0)
+    stride = n + stride_pad + (n + stride_pad) % 2
+    d_in = torch.zeros((S * stride + 8, 2), dtype=torch.float32, device=dev)
+    for s in range(S):
+        d_in[s * stride: s * stride + n] = torch.from_numpy(xs[s].view(np.float32).reshape(-1, 2))
+    nout = n // decim
+    ostride = ((nout + 3) // 4) * 4
+    d_out = torch.zeros((S, ostride), dtype=torch.float32, device=dev)
+    blk = gpu.xlating_demod(decim, proto, c["center_freq"], c["fs"], c["demod_gain"])
+    blk.set_mode(gpu.MODE_GENERIC)
+    st = torch.cuda.Stream(device=dev)
+    blk.run_captures_device(S, n, d_in, stride, d_out, ostride, st)
+    st.synchronize()
+    got = d_out.cpu().numpy()
+    for s in range(S):
+        ref = po.chain_xlating_demod(decim, proto, c["center_freq"], c["fs"], c["demod_gain"], xs[s][: nout * decim])
+        assert bits_equal(got[s, :nout], ref), s
+
+
 @pytest.mark.parametrize("decim,ntaps,stride_pad,n", [(20, 400, 0, 1_000_000), (5, 200, 63, 700_003), (3, 96, 1, 300_001),
                                                       (8, 256, 7, 500_000)])
 def test_run_captures_other_decimations(gpu, po, wl, decim, ntaps, stride_pad, n):
