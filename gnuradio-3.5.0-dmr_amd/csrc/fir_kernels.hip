@@ -271,12 +271,17 @@ struct GenericBatch { int n_streams; long long x_stride, out_stride; int n_lo, a
 // Where a block's taps come from, A/B on one box (cfg2, one 10 M-sample capture, profiles/r03_generic_ab.log): scalar loads at
 // the block's start 91.4 Gsamples/s; requested a block ahead 88.5 (the wait counter SMEM shares with LDS cannot skip a load
 // in flight, so the block's first sample wait becomes a wait for everything, and 32 more scalar registers are moved per
-// block); from LDS at a wave-uniform address 84.4 (one more LDS read per tap).
+// block); from LDS at a wave-uniform address 84.4 (one more LDS read per tap).  The scalar pair as the multiplies' operand
+// costs nothing: copied to a vector register pair first, the batch of 64 captures runs at 98.6 against 109.5
+// (profiles/r03_generic_batch_ab.log).
 #ifndef GRHIP_GW_TAPS_LDS
 #define GRHIP_GW_TAPS_LDS 0
 #endif
 #ifndef GRHIP_GW_TAP_PREFETCH
 #define GRHIP_GW_TAP_PREFETCH 0
+#endif
+#ifndef GRHIP_GW_TAPS_VGPR
+#define GRHIP_GW_TAPS_VGPR 0          // (A/B) the scalar-loaded tap copied to a vector register pair in front of its sixteen instructions
 #endif
 template <int KIND, int D, bool DEMOD>
 __global__ void __launch_bounds__(GT_T)
@@ -377,7 +382,7 @@ fir_generic_win_kernel(const float *__restrict__ taps_rev, int ntaps, const floa
                     "v_pk_add_f32 %11, %11, %3"
                     : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3),
                       "+v"(acc[j & 1][0]), "+v"(acc[j & 1][1]), "+v"(acc[j & 1][2]), "+v"(acc[j & 1][3])
-#if GRHIP_GW_TAPS_LDS
+#if GRHIP_GW_TAPS_LDS || GRHIP_GW_TAPS_VGPR
                     : "v"(ctap), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
 #else
                     : "s"(ctap), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
