@@ -229,7 +229,16 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
     float2 *ys = h->d_ystate.as<float2>();
     hipStream_t st_mm = st;         // the stream the clock recovery and the correlator run on
     bool sliced_tail = false;       // the four-level slicer has run beside the clock recovery, slice by slice
-    if (mode_fast(h->mode)) {
+    // GRHIP_MODE_GENERIC takes the same time-sliced route where its fused kernel takes batches (decimation 1 / 2 / 4): the
+    // whole chain bit-exact, the clock recovery beside a FIR that is five times the fast one -- on the same CUs (no masked
+    // streams: the vector-bound FIR wants every CU, and the loop is a tenth of its time)
+    const bool generic_sliced = !mode_fast(h->mode) && generic_demod_batch_ok(h->core.ntaps, h->core.decim, x, (long long)stream_stride_items);
+    if (generic_sliced) {
+        const float2 *gt = nullptr;                  // the rotator's phases for the whole capture, once (kept across runs)
+        rc = h->core.ensure_rot(n_out, &gt, st);
+        if (rc) return rc;
+    }
+    if (mode_fast(h->mode) || generic_sliced) {
         // FIR + demodulator in time slices on `st`; the clock recovery of a slice starts on the second stream as
         // soon as that slice is written and continues from where the previous slice left it (mm_kernel's resume
         // mode: same recurrence, same results, whatever the slicing).  The serial loop (one wavefront per capture,
@@ -252,7 +261,7 @@ int grhip_dmr_chain_run_device(grhip_dmr_chain *h, const void *d_in, size_t n_sa
         // keeps one wave per capture; a forced 8 runs with the small ring beside a FIR held to one workgroup per CU)
         const int form = h->mm_form();
         if (form != 1 && h->ncu) h->ensure_masks(h->mm_cus_wanted());
-        const bool masks = h->st_mm8 && h->st_fir8;
+        const bool masks = h->st_mm8 && h->st_fir8 && !generic_sliced;
         const bool want_rows = form != 1 && (masks || h->captures_per_wave == 8);
         // (launch_mm's `rows`: 32 = thirty-two captures per wave; else the ring of the eight-captures form)
         const int rows = !want_rows ? 0 : form == 32 && masks ? 32 : (masks && (h->S + 7) / 8 <= 4 * GRHIP_MM_CUS ? 1024 : 512);

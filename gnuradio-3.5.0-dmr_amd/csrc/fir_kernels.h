@@ -20,6 +20,7 @@ int launch_fir_generic(FirKind kind, const float *taps_rev, int ntaps, const voi
 // shapes, y_prev != y_last); returns 1 where there is no such kernel: the caller runs the two kernels instead
 // n_streams > 1 (or n_lo > 0): stream s at in + s * x_stride (x_stride even), its first n_lo items are history zeros that
 // are never read, outputs at d + s * out_stride, carries y_prev[s] / y_last[s]; the streams may start on an 8-byte boundary
+bool generic_demod_batch_ok(int ntaps, int decim, const void *in, long long x_stride);
 int launch_fir_generic_demod(const float *taps_rev, int ntaps, const void *in, float *d, long long n_out, int decim,
                              const float2 *gtab, float gain, const float *atan_tab, const float2 *y_prev, float2 *y_last,
                              hipStream_t st, int n_streams = 1, long long x_stride = 0, long long out_stride = 0,

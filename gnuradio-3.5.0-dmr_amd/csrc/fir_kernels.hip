@@ -552,6 +552,14 @@ static bool generic_tiled_ok(FirKind kind, int ntaps, const void *in, long long 
 
 // gr_fir_ccc_generic + rotator + gr_quadrature_demod_cf in one kernel (bit-exact); returns 1 where the shape has no such
 // kernel (the caller then runs the FIR and the demodulator as two)
+// the shapes launch_fir_generic_demod takes as a batch (several streams, or history zeros to synthesise)
+bool generic_demod_batch_ok(int ntaps, int decim, const void *in, long long x_stride)
+{
+    const void *row0 = (const float2 *)in - ((((uintptr_t)in) & 15) ? 1 : 0);
+    return !g_generic_no_window && (decim == 1 || decim == 2 || decim == 4) && !(x_stride & 1) &&
+           generic_tiled_ok(FIR_CCC, ntaps, row0, 2 * GT_NT, decim);
+}
+
 int launch_fir_generic_demod(const float *taps_rev, int ntaps, const void *in, float *d, long long n_out, int decim,
                              const float2 *gtab, float gain, const float *atan_tab, const float2 *y_prev, float2 *y_last,
                              hipStream_t st, int n_streams, long long x_stride, long long out_stride, long long n_lo)
@@ -560,7 +568,11 @@ int launch_fir_generic_demod(const float *taps_rev, int ntaps, const void *in, f
     // the aligned row every stream's items sit in: one item further back where the stream starts on an 8-byte boundary
     const int a_shift = (((uintptr_t)in) & 15) ? 1 : 0;
     const void *row0 = (const float2 *)in - a_shift;
-    if (g_generic_no_window || !(decim == 1 || decim == 2 || decim == 4) || !generic_tiled_ok(FIR_CCC, ntaps, row0, n_out, decim) ||
+    // (one stream with its history in front and less than two tiles of outputs: the two-kernel path; a batch of any length)
+    const bool batch = n_streams > 1 || n_lo > 0;
+    if (g_generic_no_window || !(decim == 1 || decim == 2 || decim == 4) ||
+        !generic_tiled_ok(FIR_CCC, ntaps, row0, batch && n_out < 2 * GT_NT ? 2 * GT_NT : n_out, decim) ||
+        ((n_out - 1) * decim + ntaps) * 8 >= 0x7ffffff0ll ||
         (y_prev && (const void *)y_prev == (const void *)y_last) || (n_streams > 1 && (x_stride & 1)) || n_lo < 0 || n_lo > 0x7fffffff)
         return 1;
     const GenericDemodArgs dm{d, gain, atan_tab, y_prev, y_last};

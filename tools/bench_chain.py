@@ -18,6 +18,9 @@ CPW = None
 FOUR = "--four" in sys.argv          # the 4FSK tail (pager slicer -> dibits -> correlator) instead of the binary slicer
 if FOUR:
     sys.argv.remove("--four")
+GENERIC = "--generic" in sys.argv    # the whole chain in GRHIP_MODE_GENERIC (bit-exact)
+if GENERIC:
+    sys.argv.remove("--generic")
 if "--cpw" in sys.argv:          # captures per wave of the clock recovery: 1 / 8 (default: the library's choice)
     i = sys.argv.index("--cpw")
     CPW = int(sys.argv[i + 1])
@@ -48,6 +51,8 @@ d_n = torch.zeros(S, dtype=torch.int32, device=dev)
 ch = g.dmr_chain(decim, proto, c["center_freq"], c["fs"], c["demod_gain"], omega,
                  c4["gain_omega"], c4["mu"], c4["gain_mu"], c4["omega_relative_limit"], wl.access_code_string(),
                  c4["threshold"], S, n)
+if GENERIC:
+    ch.set_mode(g.MODE_GENERIC)
 if CPW is not None:
     ch.set_captures_per_wave(CPW)
 if FOUR:
@@ -65,7 +70,7 @@ for _ in range(reps):
 e1.record(st)
 st.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(json.dumps({"workload": "full DMR chain (xlating+demod -> M&M -> slicer+correlator)", "streams": S, "four_level": FOUR, "captures_per_wave": CPW, "decim": decim,
+print(json.dumps({"workload": "full DMR chain (xlating+demod -> M&M -> slicer+correlator)", "streams": S, "four_level": FOUR, "mode": "GENERIC" if GENERIC else "FAST", "captures_per_wave": CPW, "decim": decim,
                   "ntaps": len(proto), "samples_per_stream": n, "ms_per_batch": ms, "Msamples_per_s": S * n / ms / 1e3,
                   "captures": "distinct stream ids 1000 ... %d" % (999 + S),
                   "symbols_min_max": [int(d_n.min().item()), int(d_n.max().item())],
