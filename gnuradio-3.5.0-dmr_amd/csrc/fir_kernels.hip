@@ -261,6 +261,10 @@ fir_generic_tiled_kernel(const float *__restrict__ taps_rev, int ntaps, const fl
 // d[n] needs y[n - 1]: a lane has it for three of its four outputs, gets the fourth from its neighbour through LDS, and a
 // tile starts four outputs early (its lane 0 repeats the previous tile's last four and stores nothing), so no tile waits
 // for another; d[0] takes the block's carried sample (*y_prev), the lane that holds y[n_out - 1] leaves it in *y_last.
+#ifndef GRHIP_GW_T
+#define GRHIP_GW_T 256                // lanes of a workgroup of the window kernel (A/B: 128)
+#endif
+constexpr int GW_T = GRHIP_GW_T, GW_NT = GT_R * GW_T;
 struct GenericDemodArgs { float *d; float gain; const float *atan_tab; const float2 *y_prev; float2 *y_last; };
 // Several streams in one launch (the multi-capture entries; DEMOD only): stream s reads in + s * x_stride, its first n_lo
 // items are the zeros a fresh flowgraph's history holds (never read: the pointer may lie before the capture), its outputs
@@ -284,7 +288,7 @@ struct GenericBatch { int n_streams; long long x_stride, out_stride; int n_lo, a
 #define GRHIP_GW_TAPS_VGPR 0          // (A/B) the scalar-loaded tap copied to a vector register pair in front of its sixteen instructions
 #endif
 template <int KIND, int D, bool DEMOD>
-__global__ void __launch_bounds__(GT_T)
+__global__ void __launch_bounds__(GW_T)
 fir_generic_win_kernel(const float *__restrict__ taps_rev, int ntaps, const float2 *__restrict__ in, long long n_in,
                        float2 *__restrict__ out, long long n_out, const float2 *__restrict__ gtab, const GenericDemodArgs dm,
                        const GenericBatch gb)
@@ -296,13 +300,13 @@ fir_generic_win_kernel(const float *__restrict__ taps_rev, int ntaps, const floa
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     const int t = threadIdx.x;
     const int kmax = (ntaps + D - 1) / D;                             // taps per polyphase row, at most
-    const int sub_len = GT_T + (kmax + R - 1) / R + 2;                // words per (row, slot mod 4)
+    const int sub_len = GW_T + (kmax + R - 1) / R + 2;                // words per (row, slot mod 4)
     const int per_row = R * sub_len;
     gf2 *xs = reinterpret_cast<gf2 *>(gsm);                           // [D][R][sub_len]
-    float *tp = reinterpret_cast<float *>(gsm + (size_t)D * per_row * 8 + GT_T * 8);     // (GRHIP_GW_TAPS_LDS) behind rows and s_last
+    float *tp = reinterpret_cast<float *>(gsm + (size_t)D * per_row * 8 + GW_T * 8);     // (GRHIP_GW_TAPS_LDS) behind rows and s_last
     if (GRHIP_GW_TAPS_LDS)
-        for (int i = t; i < ntaps * (KIND == FIR_CCC ? 2 : 1); i += GT_T) tp[i] = taps_rev[i];
-    constexpr int NS = DEMOD ? GT_NT - R : GT_NT;                     // new outputs per tile
+        for (int i = t; i < ntaps * (KIND == FIR_CCC ? 2 : 1); i += GW_T) tp[i] = taps_rev[i];
+    constexpr int NS = DEMOD ? GW_NT - R : GW_NT;                     // new outputs per tile
     const long long ntiles = (n_out + NS - 1) / NS;
     const int ash = gb.a_shift;
     const long long lim = n_in + ash;                                 // items of the aligned row that exist
@@ -313,12 +317,12 @@ fir_generic_win_kernel(const float *__restrict__ taps_rev, int ntaps, const floa
                                                                             (int)(lim * 8 > 0x7ffffff0ll ? 0x7ffffff0ll : lim * 8), 0x00020000);
         const long long n0 = tile * NS - (DEMOD ? R : 0);             // (DEMOD, first tile: outputs -4 .. -1 read zeros, unused)
         const long long u0 = n0 * D;                                  // first sample of the tile
-        const int span = (GT_NT - 1) * D + ntaps;                     // samples the tile touches
+        const int span = (GW_NT - 1) * D + ntaps;                     // samples the tile touches
         __syncthreads();                                              // the previous tile's reads are done
         // aligned pairs of items of the row: e = u + a_shift, even.  Items before the row or the stream's n_lo are zeros,
         // items behind its end too; a pair that straddles the end is read as one item
         const long long e0 = (u0 + ash) & ~1ll;
-        for (int mm = 2 * t; mm < span + 2; mm += 2 * GT_T) {
+        for (int mm = 2 * t; mm < span + 2; mm += 2 * GW_T) {
             const long long e = e0 + mm;
             gf4 f{0.f, 0.f, 0.f, 0.f};
             // (only items that exist are touched: the row's first n_lo + a_shift items may lie outside the allocation)
@@ -452,7 +456,7 @@ fir_generic_win_kernel(const float *__restrict__ taps_rev, int ntaps, const floa
                 y[r] = make_float2(a[0], a[1]);
                 if (gtab && n >= 0 && n < n_out) y[r] = cmul_ref(y[r], gtab[n]);
             }
-            float2 *s_last = reinterpret_cast<float2 *>(gsm + (size_t)D * per_row * 8);        // [GT_T], behind the sample rows
+            float2 *s_last = reinterpret_cast<float2 *>(gsm + (size_t)D * per_row * 8);        // [GW_T], behind the sample rows
             s_last[t] = y[R - 1];
             __syncthreads();
             if (t > 0) {
@@ -509,7 +513,7 @@ static int launch_generic_win(const float *taps_rev, int ntaps, const void *in, 
                               const GenericBatch gb = GenericBatch{1, 0, 0, 0, 0}, long long n_in_arg = -1)
 {
     const int kmax = (ntaps + D - 1) / D;
-    const size_t lds = (size_t)D * GT_R * (GT_T + (kmax + GT_R - 1) / GT_R + 2) * 8 + GT_T * 8 + (GRHIP_GW_TAPS_LDS ? (size_t)ntaps * 8 : 0);
+    const size_t lds = (size_t)D * GT_R * (GW_T + (kmax + GT_R - 1) / GT_R + 2) * 8 + GW_T * 8 + (GRHIP_GW_TAPS_LDS ? (size_t)ntaps * 8 : 0);
     static size_t cfg = 0;
     if (lds > 64 * 1024 && lds > cfg) {
         GRHIP_HIP(hipFuncSetAttribute((const void *)fir_generic_win_kernel<KIND, D, DEMOD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -518,11 +522,11 @@ static int launch_generic_win(const float *taps_rev, int ntaps, const void *in, 
     // one workgroup per tile (nothing is set up per workgroup: the taps are scalar loads): the dispatcher hands a CU its
     // next tile when one is done, so a stream of a few tiles per CU -- 10 M samples are 9.5 -- does not wait for the
     // workgroups that drew one tile more (a persistent grid of 4 per CU: 80 against 84.5 Gsamples/s on one 10 M-sample capture)
-    const long long ns = DEMOD ? GT_NT - GT_R : GT_NT;
+    const long long ns = DEMOD ? GW_NT - GT_R : GW_NT;
     const long long ntiles = (n_out + ns - 1) / ns * gb.n_streams;
     long long grid = ntiles < (1ll << 20) ? ntiles : (1ll << 20);
     const long long n_in = n_in_arg >= 0 ? n_in_arg : (n_out - 1) * D + ntaps;     // what the caller guarantees readable
-    hipLaunchKernelGGL((fir_generic_win_kernel<KIND, D, DEMOD>), dim3((unsigned)grid), dim3(GT_T), lds, st, taps_rev, ntaps,
+    hipLaunchKernelGGL((fir_generic_win_kernel<KIND, D, DEMOD>), dim3((unsigned)grid), dim3(GW_T), lds, st, taps_rev, ntaps,
                        (const float2 *)in, n_in, (float2 *)out, n_out, gtab, dm, gb);
     GRHIP_HIP(hipGetLastError());
     return GRHIP_OK;
