@@ -52,6 +52,11 @@
 #ifndef GRHIP_LG_ORDER
 #define GRHIP_LG_ORDER 1
 #endif
+#ifndef GRHIP_LG_LEAN
+#define GRHIP_LG_LEAN 0           // 1: the lean demodulator of device_math.h (seven vector instructions fewer per output, same values on cfg2) in the
+                                  // shipped kernel's epilogue: 1.225 / 1.228 ms against 1.220 / 1.239 (same box, interleaved) -- no lever, like every
+                                  // other cut of the vector work: the kernel is not bound by the vector pipe's throughput alone (profiles/r03_notes.md)
+#endif
 #ifndef GRHIP_LG_SPREAD
 #define GRHIP_LG_SPREAD 0
 #endif
@@ -235,7 +240,8 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
     const cfloat_cp stab = (cfloat_cp)a.stab;
     if (DEMOD) {
         f32x2 *at = reinterpret_cast<f32x2 *>(smem + G::OFF_ATAN);
-        for (int i = t; i < 256; i += mf::THREADS) at[i] = f32x2{a.atan_tab[i], a.atan_tab[i + 1]};
+        for (int i = t; i < 256; i += mf::THREADS)
+            at[i] = GRHIP_LG_LEAN ? f32x2{a.atan_tab[i], a.atan_tab[i + 1] - a.atan_tab[i]} : f32x2{a.atan_tab[i], a.atan_tab[i + 1]};
     }
     // staging store: sample u = 2t + 512 i  ->  byte 2u + 32 (u >> LOGQ) of each plane
     const int st_off = 4 * t + 32 * ((2 * t) >> LOGQ);
@@ -480,8 +486,8 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
                     ypendx = y0x; ypendy = y0y;
                 }
                 const float2 prev = make_float2(px, py), y1 = make_float2(y1x, y1y);
-                const float d0 = quad_demod_fast(y0, prev, a.gain, s_atan);
-                const float d1 = quad_demod_fast(y1, y0, a.gain, s_atan);
+                const float d0 = GRHIP_LG_LEAN ? quad_demod_lean(y0, prev, a.gain, s_atan) : quad_demod_fast(y0, prev, a.gain, s_atan);
+                const float d1 = GRHIP_LG_LEAN ? quad_demod_lean(y1, y0, a.gain, s_atan) : quad_demod_fast(y1, y0, a.gain, s_atan);
                 if (b == 0) d1_pend = d1;
                 const bool st_ok = own && !(b == 0 && r8 == 0);     // (a segment's first pair waits for its predecessor)
                 const f32x2 dd{d0, d1};
@@ -647,7 +653,8 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
             // first output of every segment but the wave's first: predecessor = last output of the
             // segment before, i.e. the second output of the lane before, after the last block
             const float px = __shfl_up(y1x, 1), py = __shfl_up(y1y, 1);
-            const float dp = quad_demod_fast(make_float2(ypendx, ypendy), make_float2(px, py), a.gain, s_atan);
+            const float dp = GRHIP_LG_LEAN ? quad_demod_lean(make_float2(ypendx, ypendy), make_float2(px, py), a.gain, s_atan)
+                                           : quad_demod_fast(make_float2(ypendx, ypendy), make_float2(px, py), a.gain, s_atan);
             const bool st_ok = r8 == 0 && rsl != 0 && n_base >= 0;
             const f32x2 dd{dp, d1_pend};
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, dd), orsrc, st_ok ? 4 * n_base : OOB, 0, 0);
