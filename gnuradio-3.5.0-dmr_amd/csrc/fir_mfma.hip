@@ -52,6 +52,9 @@
 #ifndef GRHIP_LG_ORDER
 #define GRHIP_LG_ORDER 1
 #endif
+#ifndef GRHIP_MF_WGS
+#define GRHIP_MF_WGS 2            // workgroups per CU the shipped kernel is compiled and launched for (experiment: 3 with GRHIP_MF_NBLK=2)
+#endif
 #ifndef GRHIP_LG_LEAN
 #define GRHIP_LG_LEAN 0           // 1: the lean demodulator of device_math.h (seven vector instructions fewer per output, same values on cfg2) in the
                                   // shipped kernel's epilogue: 1.225 / 1.228 ms against 1.220 / 1.239 (same box, interleaved) -- no lever, like every
@@ -97,7 +100,7 @@ template <int D, int KS> struct Geo {
     static constexpr int LDS = OFF_G + mf::NG * 64 * 16;
     static_assert((1 << LOGQ) == Q, "segment stride must be a power of two");
     static_assert(HALO >= 0 && HALO % 32 == 0, "halo");
-    static_assert(mf::plane_pos(mf::WAVE_NEW * D - 1, D) + 2 - mf::plane_pos(HALO, D) >= SCR_WAVE * 4, "a wave's own stretch of a plane must hold one accumulator tile");
+    static_assert(mf::NBLK != 4 || mf::plane_pos(mf::WAVE_NEW * D - 1, D) + 2 - mf::plane_pos(HALO, D) >= SCR_WAVE * 4, "a wave's own stretch of a plane must hold one accumulator tile");
     static_assert(mf::ROUND % Q == 0, "a staging round must cover whole segment strides");
 };
 
@@ -191,7 +194,7 @@ struct AtanPairs {
 }  // namespace
 
 template <int D, int KS, bool PREMIX, int EPI, bool TAPQ = false>
-__global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaArgs a)
+__global__ void __launch_bounds__(mf::THREADS, GRHIP_MF_WGS) fir_mfma_kernel(const FirMfmaArgs a)
 {
     static_assert(!TAPQ || PREMIX, "the tap-angle correction belongs to freq_xlating's pre-mix form");
     using G = Geo<D, KS>;
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(mf::THREADS, 2) fir_mfma_kernel(const FirMfmaA
     };
     // part < 0: all rounds; else the part-th quarter
     auto fetch = [&](__amdgpu_buffer_rsrc_t rsrc, int voff, int part_) __attribute__((always_inline)) {
-        constexpr int PER = (NI + 3) / 4;
+        constexpr int PER = (NI + NBLK - 1) / NBLK;       // (a share of the next tile's loads per block)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             if (part_ >= 0 && i / PER != part_) continue;
@@ -715,7 +718,7 @@ extern "C" __attribute__((visibility("default"))) int grdbg_set_stamp_buffer_mfm
 #endif
 
 
-#ifdef GRHIP_DIAG       // (diagnostic builds only: see launch_mfma_inst)
+#if defined(GRHIP_DIAG) && GRHIP_MF_NBLK == 4       // (diagnostic builds only: see launch_mfma_inst)
 // =================================================================================================
 // fir_mfma_rs_kernel -- the same engine with the waves of a workgroup in two ROLES (round 3)
 // =================================================================================================
@@ -1276,10 +1279,8 @@ static int launch_mfma_inst(const FirMfmaArgs &a, hipStream_t st)
     // diagnostic builds only, selected with GRHIP_MF_RS=1: ten versions of it tied with or lost to the kernel above by 0-6 %
     // (DESIGN 4.0a has the A/B table, the stamps and the ablations that say why).
     bool role_split = false;
-#ifdef GRHIP_DIAG
+#if defined(GRHIP_DIAG) && GRHIP_MF_NBLK == 4
     if (const char *e = getenv("GRHIP_MF_RS")) role_split = atoi(e) != 0 && a.max_wg_per_cu != 1;
-#endif
-#ifdef GRHIP_DIAG
     if (role_split) {
         using R = GeoRS<D, KS>;
         auto kern_rs = fir_mfma_rs_kernel<D, KS, PREMIX, EPI>;
@@ -1297,7 +1298,7 @@ static int launch_mfma_inst(const FirMfmaArgs &a, hipStream_t st)
 #endif
     (void)role_split;
     int wgs = (160 * 1024) / (G::LDS + 256);
-    if (wgs > 2) wgs = 2;
+    if (wgs > GRHIP_MF_WGS) wgs = GRHIP_MF_WGS;
     if (a.max_wg_per_cu > 0 && wgs > a.max_wg_per_cu) wgs = a.max_wg_per_cu;
     if (wgs < 1) wgs = 1;
     long long grid = (long long)wgs * (a.max_cus > 0 && a.max_cus < g_mf_cus ? a.max_cus : g_mf_cus);

@@ -25,7 +25,10 @@ namespace mf {
 constexpr int THREADS = 256, WAVES = 4;
 constexpr int SEGS = 8;             // stream segments per wave = MFMA column pairs
 constexpr int BLK = 16;             // outputs per MFMA block (rows of A)
-constexpr int NBLK = 4;             // blocks per segment
+#ifndef GRHIP_MF_NBLK
+#define GRHIP_MF_NBLK 4             // (experiment: 2 = tiles of half the size)
+#endif
+constexpr int NBLK = GRHIP_MF_NBLK; // blocks per segment
 constexpr int SEG_OUT = BLK * NBLK; // 64
 constexpr int WAVE_OUT = SEGS * SEG_OUT;        // 512 outputs computed per wave
 constexpr int WAVE_NEW = WAVE_OUT - BLK;        // 496: the first block of a wave only hands its last output on
