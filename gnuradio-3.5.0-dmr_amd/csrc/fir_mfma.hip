@@ -55,6 +55,12 @@
 #ifndef GRHIP_MF_WGS
 #define GRHIP_MF_WGS 2            // workgroups per CU the shipped kernel is compiled and launched for (experiment: 3 with GRHIP_MF_NBLK=2)
 #endif
+#ifndef GRHIP_LG_EPI2
+#define GRHIP_LG_EPI2 0
+#endif
+#ifndef GRHIP_LG_STAGE2
+#define GRHIP_LG_STAGE2 1         // the pre-mix staging two rounds at a time in a hand-ordered block (0: a round at a time, the compiler's order)
+#endif
 #ifndef GRHIP_LG_LEAN
 #define GRHIP_LG_LEAN 0           // 1: the lean demodulator of device_math.h (seven vector instructions fewer per output, same values on cfg2) in the
                                   // shipped kernel's epilogue: 1.225 / 1.228 ms against 1.220 / 1.239 (same box, interleaved) -- no lever, like every
@@ -375,6 +381,77 @@ __global__ void __launch_bounds__(mf::THREADS, GRHIP_MF_WGS) fir_mfma_kernel(con
 #else
 #define MF_EXP_SKIP(bit)
 #endif
+#if GRHIP_LG_STAGE2
+        // The pre-mix form's rounds two at a time in ONE hand-ordered block: a round is a chain of ten dependent packed
+        // instructions (phasor = lane phasor x round phasor, sample x phasor, convert, split), hipcc 7.2 emits the rounds one
+        // after the other with every instruction waiting for the one before it (the register file is full: nothing to
+        // interleave with), and with two waves per SIMD the staging phase was a third of a wave's time (stamps,
+        // profiles/r03_notes.md).  Here the four chains of two rounds (two samples each) advance in step, so every
+        // instruction's operands are four issues old; the round phasors come as scalar pairs.
+        if (PREMIX) MF_EXP_SKIP(2)
+        {
+            const f32x2 ws0 = wl * scale, ws1 = wl1 * scale;
+            unsigned char *dst = smem + st_off;
+            auto store_round = [&](int i, unsigned rh, unsigned rlo, unsigned ih, unsigned ilo) __attribute__((always_inline)) {
+                if ((i + 1) * mf::ROUND <= SP || 2 * t + i * mf::ROUND < SP) {
+                    unsigned char *d = dst + i * ST_STEP;
+                    *reinterpret_cast<unsigned *>(d) = rh;
+                    *reinterpret_cast<unsigned *>(d + PL) = rlo;
+                    *reinterpret_cast<unsigned *>(d + 2 * PL) = ih;
+                    *reinterpret_cast<unsigned *>(d + 3 * PL) = ilo;
+                }
+            };
+            // cmul(a, b) = v_pk_mul t, a, b [1,1][1,0] neg_lo:[0,1]; v_pk_fma r, a, b, t [0,1,1]   (device_math.h cmul_pk)
+#define MF_CM1(t, a, b) "v_pk_mul_f32 " t ", " a ", " b " op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+#define MF_CM2(r, a, b, t) "v_pk_fma_f32 " r ", " a ", " b ", " t " op_sel_hi:[0,1,1]\n\t"
+            int i = 0;
+#pragma unroll
+            for (; i + 1 < NI; i += 2) {
+                const f32x2 Sa{stab[2 * i], stab[2 * i + 1]}, Sb{stab[2 * i + 2], stab[2 * i + 3]};
+                f32x2 a0{pf[i][0], pf[i][1]}, a1{pf[i][2], pf[i][3]}, b0{pf[i + 1][0], pf[i + 1][1]}, b1{pf[i + 1][2], pf[i + 1][3]};
+                f32x2 t0, t1, t2, t3, p0, p1, p2, p3;
+                unsigned arh, aih, arl, ail, brh, bih, brl, bil;
+                asm(MF_CM1("%0", "%12", "%14") MF_CM1("%1", "%13", "%14") MF_CM1("%2", "%12", "%15") MF_CM1("%3", "%13", "%15")
+                    MF_CM2("%4", "%12", "%14", "%0") MF_CM2("%5", "%13", "%14", "%1") MF_CM2("%6", "%12", "%15", "%2") MF_CM2("%7", "%13", "%15", "%3")
+                    MF_CM1("%0", "%8", "%4") MF_CM1("%1", "%9", "%5") MF_CM1("%2", "%10", "%6") MF_CM1("%3", "%11", "%7")
+                    MF_CM2("%8", "%8", "%4", "%0") MF_CM2("%9", "%9", "%5", "%1") MF_CM2("%10", "%10", "%6", "%2") "v_pk_fma_f32 %11, %11, %7, %3 op_sel_hi:[0,1,1]"
+                    : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3),
+                      "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)
+                    : "v"(ws0), "v"(ws1), "s"(Sa), "s"(Sb));
+                // (re, im) of the two samples of each round -> high halves, then low halves, the four registers in step
+                asm("v_cvt_pk_f16_f32 %0, %8, %10\n\t"
+                    "v_cvt_pk_f16_f32 %1, %9, %11\n\t"
+                    "v_cvt_pk_f16_f32 %4, %12, %14\n\t"
+                    "v_cvt_pk_f16_f32 %5, %13, %15\n\t"
+                    "v_fma_mixlo_f16 %2, %8, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mixlo_f16 %3, %9, 1.0, -%1 op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mixlo_f16 %6, %12, 1.0, -%4 op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mixlo_f16 %7, %13, 1.0, -%5 op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mixhi_f16 %2, %10, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mixhi_f16 %3, %11, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mixhi_f16 %6, %14, 1.0, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mixhi_f16 %7, %15, 1.0, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                    : "=&v"(arh), "=&v"(aih), "=&v"(arl), "=&v"(ail), "=&v"(brh), "=&v"(bih), "=&v"(brl), "=&v"(bil)
+                    : "v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y));
+                store_round(i, arh, arl, aih, ail);
+                store_round(i + 1, brh, brl, bih, bil);
+            }
+            if (i < NI) {                          // the odd round out: the two chains of one round
+                const f32x2 S{stab[2 * i], stab[2 * i + 1]};
+                f32x2 e0{pf[i][0], pf[i][1]}, e1{pf[i][2], pf[i][3]};
+                e0 = cmul_pk(e0, cmul_pk(ws0, S));
+                e1 = cmul_pk(e1, cmul_pk(ws1, S));
+                const f32x2 re{e0.x, e1.x}, im{e0.y, e1.y};
+                const h16x2 rh = __builtin_convertvector(re, h16x2), ih = __builtin_convertvector(im, h16x2);
+                const h16x2 rlo = split_lo(re, rh), ilo = split_lo(im, ih);
+                store_round(i, __builtin_bit_cast(unsigned, rh), __builtin_bit_cast(unsigned, rlo), __builtin_bit_cast(unsigned, ih),
+                            __builtin_bit_cast(unsigned, ilo));
+            }
+#undef MF_CM1
+#undef MF_CM2
+        }
+        else
+#endif
         MF_EXP_SKIP(2)
         {
             const f32x2 ws0 = wl * scale, ws1 = wl1 * scale;
@@ -650,7 +727,8 @@ __global__ void __launch_bounds__(mf::THREADS, GRHIP_MF_WGS) fir_mfma_kernel(con
             const f32x4 yv = yv_n;
             if (b + 1 < NBLK) yv_n = read_block(b + 1);
             epilogue(b, yv);
-            __builtin_amdgcn_sched_barrier(0);
+            // (GRHIP_LG_EPI2: the scheduler may interleave the blocks of a pair -- four demodulator chains in step instead of two)
+            if (!GRHIP_LG_EPI2 || (b & 1) || !DEMOD) __builtin_amdgcn_sched_barrier(0);
         }
         if (DEMOD) {
             // first output of every segment but the wave's first: predecessor = last output of the

@@ -1,0 +1,6 @@
+# shipped FIR kernel: the epilogue's blocks in pairs (epi2) against one at a time (diag); parity of the variant first
+mkdir -p gpurun_out
+L=$PWD/gnuradio-3.5.0-dmr_amd
+GRHIP_LIB=$L/libgrhip_epi2.so timeout -k 10 900 python -m pytest tests/test_gpu_fir_mfma.py tests/test_gpu_fir.py -x -q > gpurun_out/epi2_tests.log 2>&1; rc=$?; tail -2 gpurun_out/epi2_tests.log
+[ $rc -eq 0 ] || exit $rc
+VARIANTS="GRHIP_LIB=$L/libgrhip_diag.so GRHIP_LIB=$L/libgrhip_epi2.so" bash tools/gpu_ab.sh > gpurun_out/epi2_ab.log 2>&1; cat gpurun_out/epi2_ab.log
