@@ -56,7 +56,7 @@
 #define GRHIP_MF_WGS 2            // workgroups per CU the shipped kernel is compiled and launched for (experiment: 3 with GRHIP_MF_NBLK=2)
 #endif
 #ifndef GRHIP_LG_EPI2
-#define GRHIP_LG_EPI2 0
+#define GRHIP_LG_EPI2 0             // 1: the epilogue's blocks in pairs (four demodulator chains for the scheduler): 1.208 / 1.205 ms against 1.204 / 1.202
 #endif
 #ifndef GRHIP_LG_STAGE2
 #define GRHIP_LG_STAGE2 1         // the pre-mix staging two rounds at a time in a hand-ordered block (0: a round at a time, the compiler's order)
