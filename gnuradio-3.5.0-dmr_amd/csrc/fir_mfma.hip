@@ -55,6 +55,9 @@
 #ifndef GRHIP_MF_WGS
 #define GRHIP_MF_WGS 2            // workgroups per CU the shipped kernel is compiled and launched for (experiment: 3 with GRHIP_MF_NBLK=2)
 #endif
+#ifndef GRHIP_LG_MAX4
+#define GRHIP_LG_MAX4 1
+#endif
 #ifndef GRHIP_LG_EPI2
 #define GRHIP_LG_EPI2 0             // 1: the epilogue's blocks in pairs (four demodulator chains for the scheduler): 1.208 / 1.205 ms against 1.204 / 1.202
 #endif
@@ -330,12 +333,20 @@ __global__ void __launch_bounds__(mf::THREADS, GRHIP_MF_WGS) fir_mfma_kernel(con
 
         // ---- block floating point: the tile's largest |component| ---------------------
         {
-            float m = 0.f;
+            // (four running maxima: one would be a chain of 2 NI dependent instructions at the top of every tile)
+            float m = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(pf[i][0]), "v"(pf[i][1]));
-                asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(pf[i][2]), "v"(pf[i][3]));
+                if (GRHIP_LG_MAX4 && (i & 1)) {
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m2) : "v"(pf[i][0]), "v"(pf[i][1]));
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m3) : "v"(pf[i][2]), "v"(pf[i][3]));
+                } else {
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(pf[i][0]), "v"(pf[i][1]));
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(GRHIP_LG_MAX4 ? m1 : m) : "v"(pf[i][2]), "v"(pf[i][3]));
+                }
             }
+            asm("v_max3_f32 %0, %1, %2, %0" : "+v"(m) : "v"(m1), "v"(m2));       // (the same instruction: a non-finite sample is treated
+            asm("v_max3_f32 %0, %1, %1, %0" : "+v"(m) : "v"(m3));                // as in the single chain)
             m = wave_max_nonneg(m);
             if (!(m < __builtin_inff())) {          // an Inf / NaN sample: the scale comes from the finite ones (see fir_mfma_rs_kernel)
                 float mf = 0.f;
