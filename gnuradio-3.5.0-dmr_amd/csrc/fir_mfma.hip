@@ -56,7 +56,7 @@
 #define GRHIP_MF_WGS 2            // workgroups per CU the shipped kernel is compiled and launched for (experiment: 3 with GRHIP_MF_NBLK=2)
 #endif
 #ifndef GRHIP_LG_MAX4
-#define GRHIP_LG_MAX4 1
+#define GRHIP_LG_MAX4 0             // 1: four running maxima instead of one chain of 2 NI dependent v_max3: 1.205 / 1.176 ms against 1.192 / 1.178 -- nothing
 #endif
 #ifndef GRHIP_LG_EPI2
 #define GRHIP_LG_EPI2 0             // 1: the epilogue's blocks in pairs (four demodulator chains for the scheduler): 1.208 / 1.205 ms against 1.204 / 1.202
