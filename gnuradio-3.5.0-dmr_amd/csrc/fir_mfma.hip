@@ -345,8 +345,10 @@ __global__ void __launch_bounds__(mf::THREADS, GRHIP_MF_WGS) fir_mfma_kernel(con
                     asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(GRHIP_LG_MAX4 ? m1 : m) : "v"(pf[i][2]), "v"(pf[i][3]));
                 }
             }
-            asm("v_max3_f32 %0, %1, %2, %0" : "+v"(m) : "v"(m1), "v"(m2));       // (the same instruction: a non-finite sample is treated
-            asm("v_max3_f32 %0, %1, %1, %0" : "+v"(m) : "v"(m3));                // as in the single chain)
+            if (GRHIP_LG_MAX4) {
+                asm("v_max3_f32 %0, %1, %2, %0" : "+v"(m) : "v"(m1), "v"(m2));   // (the same instruction: a non-finite sample is treated
+                asm("v_max3_f32 %0, %1, %1, %0" : "+v"(m) : "v"(m3));            // as in the single chain)
+            }
             m = wave_max_nonneg(m);
             if (!(m < __builtin_inff())) {          // an Inf / NaN sample: the scale comes from the finite ones (see fir_mfma_rs_kernel)
                 float mf = 0.f;
