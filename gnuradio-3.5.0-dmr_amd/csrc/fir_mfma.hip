@@ -55,6 +55,10 @@
 #ifndef GRHIP_MF_WGS
 #define GRHIP_MF_WGS 2            // workgroups per CU the shipped kernel is compiled and launched for (experiment: 3 with GRHIP_MF_NBLK=2)
 #endif
+#ifndef GRHIP_LG_SPF
+#define GRHIP_LG_SPF 0              // 1: the staging's round phasors (scalar loads) requested a pair of rounds ahead, the first ones before the barrier:
+                                    // 1.1859 / 1.1865 ms against 1.1854 / 1.1903 -- nothing
+#endif
 #ifndef GRHIP_LG_MAX4
 #define GRHIP_LG_MAX4 0             // 1: four running maxima instead of one chain of 2 NI dependent v_max3: 1.205 / 1.176 ms against 1.192 / 1.178 -- nothing
 #endif
@@ -331,6 +335,11 @@ __global__ void __launch_bounds__(mf::THREADS, GRHIP_MF_WGS) fir_mfma_kernel(con
         int s_nxt, b_nxt;
         MF_STAMP(7);
 
+#if GRHIP_LG_STAGE2
+        // (the first two round phasors of the staging below, requested a phase and a barrier ahead of their use)
+        f32x2 Sa_first{0.f, 0.f}, Sb_first{0.f, 0.f};
+        if (PREMIX && GRHIP_LG_SPF) { Sa_first = f32x2{stab[0], stab[1]}; Sb_first = f32x2{stab[2], stab[3]}; }
+#endif
         // ---- block floating point: the tile's largest |component| ---------------------
         {
             // (four running maxima: one would be a chain of 2 NI dependent instructions at the top of every tile)
@@ -418,9 +427,19 @@ __global__ void __launch_bounds__(mf::THREADS, GRHIP_MF_WGS) fir_mfma_kernel(con
 #define MF_CM1(t, a, b) "v_pk_mul_f32 " t ", " a ", " b " op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
 #define MF_CM2(r, a, b, t) "v_pk_fma_f32 " r ", " a ", " b ", " t " op_sel_hi:[0,1,1]\n\t"
             int i = 0;
+            // (the round phasors are scalar loads: those of the next pair of rounds are requested before this pair's blocks,
+            // or every pair would start with a wait for the scalar cache)
+            f32x2 Sa = Sa_first, Sb = Sb_first;
+            if (!GRHIP_LG_SPF) { Sa = f32x2{stab[0], stab[1]}; Sb = f32x2{stab[2], stab[3]}; }
 #pragma unroll
             for (; i + 1 < NI; i += 2) {
-                const f32x2 Sa{stab[2 * i], stab[2 * i + 1]}, Sb{stab[2 * i + 2], stab[2 * i + 3]};
+                f32x2 Sa_n = Sa, Sb_n = Sb;
+                if (GRHIP_LG_SPF) {
+                    if (i + 2 < NI) Sa_n = f32x2{stab[2 * i + 4], stab[2 * i + 5]};
+                    if (i + 3 < NI) Sb_n = f32x2{stab[2 * i + 6], stab[2 * i + 7]};
+                } else if (i > 0) {
+                    Sa = f32x2{stab[2 * i], stab[2 * i + 1]}; Sb = f32x2{stab[2 * i + 2], stab[2 * i + 3]};
+                }
                 f32x2 a0{pf[i][0], pf[i][1]}, a1{pf[i][2], pf[i][3]}, b0{pf[i + 1][0], pf[i + 1][1]}, b1{pf[i + 1][2], pf[i + 1][3]};
                 f32x2 t0, t1, t2, t3, p0, p1, p2, p3;
                 unsigned arh, aih, arl, ail, brh, bih, brl, bil;
@@ -448,9 +467,10 @@ __global__ void __launch_bounds__(mf::THREADS, GRHIP_MF_WGS) fir_mfma_kernel(con
                     : "v"(a0.x), "v"(a0.y), "v"(a1.x), "v"(a1.y), "v"(b0.x), "v"(b0.y), "v"(b1.x), "v"(b1.y));
                 store_round(i, arh, arl, aih, ail);
                 store_round(i + 1, brh, brl, bih, bil);
+                if (GRHIP_LG_SPF) { Sa = Sa_n; Sb = Sb_n; }
             }
             if (i < NI) {                          // the odd round out: the two chains of one round
-                const f32x2 S{stab[2 * i], stab[2 * i + 1]};
+                const f32x2 S = GRHIP_LG_SPF ? Sa : f32x2{stab[2 * i], stab[2 * i + 1]};
                 f32x2 e0{pf[i][0], pf[i][1]}, e1{pf[i][2], pf[i][3]};
                 e0 = cmul_pk(e0, cmul_pk(ws0, S));
                 e1 = cmul_pk(e1, cmul_pk(ws1, S));
